@@ -1,0 +1,29 @@
+# Top-level build: the product library (HIP, gfx950 only), the host-side library, the oracle.
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+PKG      := vulkan_raytracing_amd
+CSRC     := $(PKG)/csrc
+# -ffp-contract=off: the kernels' arithmetic is the canonical sequence of DESIGN.md; only explicit
+# __builtin_fmaf fuses.  Division and sqrt stay IEEE-correct (hipcc default).
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Iinclude
+
+all: $(PKG)/librt_mi355x.so oracle
+
+$(PKG)/librt_mi355x.so: $(CSRC)/kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/bvh_build.h include/rt_api.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp
+
+oracle:
+	$(MAKE) -C oracle all
+
+resource-usage:
+	$(HIPCC) $(HIPFLAGS) -c -Rpass-analysis=kernel-resource-usage -o /dev/null $(CSRC)/kernels.hip
+
+clean:
+	rm -f $(PKG)/*.so; $(MAKE) -C oracle clean
+.PHONY: all oracle clean resource-usage
+
+# host-side library (OBJ/MTL ingest, camera, animation, stand-in mesh, JPEG decode) — g++ only
+HOSTSRC := $(CSRC)/host_shim.cpp host/camera.cpp host/standin.cpp $(wildcard host/jpeg_decode.cpp)
+$(PKG)/librt_host.so: $(HOSTSRC) include/rt_host.hpp include/obj_loader.h include/camera.h include/rt_vec.h include/config.h include/rt_api.h
+	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -o $@ $(HOSTSRC)
+all: $(PKG)/librt_host.so

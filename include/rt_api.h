@@ -1,0 +1,167 @@
+/* rt_api.h — C ABI of librt_mi355x.so, the MI355X (gfx950) replacement for the reference's
+ * VK_KHR_ray_tracing_pipeline stage.
+ *
+ * The reference (mcan1999/vulkan-raytracing) reaches its ray-tracing stage through raw Vulkan calls
+ * inlined in main(); it has no plugin/FFI interface.  This header cuts the seam at the Vulkan
+ * objects the host creates for that stage: one export per Vulkan interaction on the path.  Each
+ * declaration cites the reference call site it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every call returns 0 on success (mirrors VK_SUCCESS); non-zero = rt_status below, message via
+ *     rt_last_error().  No exception crosses the boundary (the reference throws
+ *     std::runtime_error("Vulkan API exception...") from throwExceptionVulkanAPI, src/main.cpp:138-147;
+ *     the C++ host wrapper host/rt_host.hpp re-throws to keep that behaviour).
+ *   - the caller owns every host array; the library copies on upload (as copyData does,
+ *     src/main.cpp:203-219).  Handles are opaque; destroy is explicit.
+ *   - one context drives one GPU and is not re-entrant (the reference is single-threaded with one
+ *     queue and a blocking fence after every build/upload).
+ *   - plain pointers and sizes only; no torch / HIP types in signatures (streams are void*).
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum rt_status {
+  RT_OK = 0,
+  RT_ERR_INVALID_ARGUMENT = 1,
+  RT_ERR_NOT_READY = 2,      /* call order violated (e.g. trace before geometry/instances/uniforms) */
+  RT_ERR_DEVICE = 3,         /* a HIP runtime call failed; see rt_last_error */
+  RT_ERR_OUT_OF_MEMORY = 4,
+  RT_ERR_NO_DEVICE = 5       /* no usable gfx950 device: the library never falls back to the CPU */
+};
+
+/* One object of the shared vertex/index buffers (generalises orbitingObjectVertexOffset /
+ * orbitingObjectPrimitiveOffset, src/main.cpp:1872-1873). */
+typedef struct rt_mesh_range {
+  uint64_t first_float;   /* offset into verts6, in floats (= vertexOffset of src/shader.rchit:55) */
+  uint64_t first_index;   /* offset into idx, in uint32s (= 3*primitiveOffset) */
+  uint32_t prim_count;    /* triangles (src/main.cpp:1644) */
+  uint32_t reserved;
+} rt_mesh_range;
+
+/* 64-byte mirror of VkAccelerationStructureInstanceKHR as filled by createInstance
+ * (src/main.cpp:538-551): a maintainer can memcpy the Vulkan struct and overwrite the last field. */
+typedef struct rt_instance {
+  float transform[12];              /* row-major 3x4 object->world (glmToVulkan, src/main.cpp:245-249) */
+  uint32_t custom_index_and_mask;   /* instanceCustomIndex:24 (low) | mask:8 (high) */
+  uint32_t sbt_offset_and_flags;    /* instanceShaderBindingTableRecordOffset:24 | flags:8 (ignored: the
+                                       reference always uses offset 0 / TRIANGLE_FACING_CULL_DISABLE) */
+  uint64_t mesh;                    /* index into rt_mesh_range[] — replaces accelerationStructureReference */
+} rt_instance;
+
+/* The 104-byte UniformStructure, field for field (src/main.cpp:1847-1866; src/shader.rgen:22-46). */
+typedef struct rt_uniforms {
+  float position[4];
+  float right[4];
+  float up[4];
+  float forward[4];
+  float light_position[3];
+  float light_intensity;
+  uint32_t max_bounce_count;
+  uint32_t samples_per_pixel;
+  uint32_t center_object_type;      /* 0 diffuse, 1 mirror, 2 refractive (include/config.h:9-16) */
+  uint32_t orbiting_object_type;
+  uint32_t orbiting_object_primitive_offset;  /* informational: ranges[] is authoritative */
+  uint32_t orbiting_object_vertex_offset;
+} rt_uniforms;
+
+/* Result of one traceRayEXT (src/shader.rgen:86-87 / 111-112): what the driver hands to rchit/rmiss. */
+typedef struct rt_hit {
+  float t, u, v;        /* gl_HitTEXT and hitAttributeEXT vec2 (barycentrics of vertices B, C) */
+  int32_t prim;         /* gl_PrimitiveID; -1 on miss */
+  int32_t inst;         /* index into the instance array (gl_InstanceID); -1 on miss */
+} rt_hit;
+
+typedef struct rt_stats {
+  uint64_t rays_primary;     /* one count per traceRayEXT-equivalent, by class */
+  uint64_t rays_secondary;
+  uint64_t rays_shadow;
+  uint64_t node_visits;      /* filled only by rt_trace_counting (instrumented kernels) */
+  uint64_t tri_tests;
+  uint64_t closest_rays;     /* rays through the closest-hit traversal kernel (primary+secondary) */
+  float ms_frame;            /* HIP-event time of the whole frame pipeline on the trace stream */
+  float ms_raygen;
+  float ms_trace_closest;    /* sum over bounces of the closest-hit traversal kernel */
+  float ms_trace_shadow;     /* any-hit traversal kernel */
+  float ms_shade;
+  float ms_resolve;
+  uint32_t launches_trace_closest;
+  uint32_t launches_total;
+  uint32_t bvh_node_bytes;   /* S_node, S_tri of the roofline formula */
+  uint32_t bvh_tri_bytes;
+} rt_stats;
+
+/* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */
+int rt_create(rt_ctx** out_ctx, int device_id);
+/* Cleanup (src/main.cpp:2977-3060). */
+void rt_destroy(rt_ctx* ctx);
+
+/* buildBuffer for the shared vertex and index buffers (src/main.cpp:1684-1697, 1713-1726).
+ * verts6 = interleaved [px py pz nx ny nz] (src/main.cpp:1673-1682), idx = object-local uint32. */
+int rt_upload_geometry(rt_ctx* ctx, const float* verts6, size_t n_floats, const uint32_t* idx, size_t n_idx,
+                       const rt_mesh_range* ranges, int n_meshes);
+
+/* createBLASGeometry + createBLAS + createBLASScratchBuffer + buildBLAS (src/main.cpp:305-536, called
+ * :1734-1799).  Synchronous like the reference's fence wait (:525-527). */
+int rt_build_blas(rt_ctx* ctx, int mesh);
+
+/* createInstance + createTLAS (src/main.cpp:538-793; called :1818-1835 with update=false and every
+ * frame :2848-2861 with update=true).  update!=0 keeps the TLAS topology and refits boxes (Vulkan
+ * UPDATE mode, src=dst); it requires the same instance count as the last build. */
+int rt_set_instances(rt_ctx* ctx, const rt_instance* instances, int n, int update);
+
+/* Uniform buffer copyData (src/main.cpp:1887-1889, 2901-2903). */
+int rt_set_uniforms(rt_ctx* ctx, const rt_uniforms* u);
+
+/* Cube map creation + upload (src/main.cpp:2073-2412): 6 RGBA8 faces in the order
+ * right,left,top,bottom,front,back (:2064-2071) = +X,-X,+Y,-Y,+Z,-Z, all w x h. */
+int rt_set_skybox(rt_ctx* ctx, const uint8_t* const faces_rgba8[6], int w, int h);
+
+/* vkCmdTraceRaysKHR(W,H,1) + the image copy (src/main.cpp:2620-2624, 2683-2686).  Blocking; writes the
+ * whole frame (row 0 = top, RGBA32F, the shader's declared rgba32f format src/shader.rgen:48) to host. */
+int rt_trace(rt_ctx* ctx, int width, int height, float* out_rgba32f_host, rt_stats* stats);
+
+/* Sharded, asynchronous form used for multi-GPU tiling (one process per GPU).  Renders the row bands
+ * {b : b % n_shards == shard} of band_rows rows each and writes them COMPACTLY (band after band, each
+ * band_rows x width x 4 floats; the last band of the frame may be short) into d_out, a DEVICE pointer
+ * owned by the caller (e.g. a torch tensor), enqueued on hip_stream (NULL = the context's stream).
+ * Returns immediately; use rt_synchronize / the stream to wait.  out_capacity_bytes guards d_out. */
+int rt_trace_shard(rt_ctx* ctx, int width, int height, int band_rows, int shard, int n_shards,
+                   void* d_out, size_t out_capacity_bytes, void* hip_stream);
+/* number of rows rt_trace_shard writes for (height, band_rows, shard, n_shards) */
+int rt_shard_rows(int height, int band_rows, int shard, int n_shards);
+
+/* Wait for the last enqueued frame and read its counters / HIP-event timings. */
+int rt_synchronize(rt_ctx* ctx);
+int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
+/* Enable per-kernel hipEvent timing (adds event records to the stream; default off). */
+int rt_set_timing(rt_ctx* ctx, int enabled);
+
+/* Record-level entry for traceRayEXT alone (rows a10/a14): n rays of 8 floats (o.xyz, tmin, d.xyz, tmax)
+ * from host memory; any_hit!=0 = TerminateOnFirstHit|SkipClosestHit (src/shader.rgen:67). Blocking.
+ * counting!=0 runs the instrumented kernel and fills stats->node_visits / tri_tests. */
+int rt_intersect(rt_ctx* ctx, size_t n, const float* rays8_host, int any_hit, rt_hit* out_host, int counting,
+                 rt_stats* stats);
+
+/* Same frame as rt_trace but through the instrumented traversal kernels (visit counters). */
+int rt_trace_counting(rt_ctx* ctx, int width, int height, float* out_rgba32f_host, rt_stats* stats);
+
+/* Message of the last failing call on this context (or of rt_create when ctx==NULL). */
+const char* rt_last_error(const rt_ctx* ctx);
+/* "gfx950 <device name> CUs=<n>" of the bound device. */
+const char* rt_device_info(const rt_ctx* ctx);
+/* ABI version: bumped on any signature/layout change. */
+int rt_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */

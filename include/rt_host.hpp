@@ -1,0 +1,190 @@
+// rt_host.hpp — C++ host side above the C ABI (include/rt_api.h): the reference's own host steps
+// for the ray-tracing path, restated headless.  Each function cites the reference code it mirrors
+// (paths relative to the reference root).  Errors surface as std::runtime_error, as the reference's
+// throwExceptionVulkanAPI does (src/main.cpp:138-147).
+#ifndef RT_HOST_HPP
+#define RT_HOST_HPP
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "config.h"
+#include "obj_loader.h"
+#include "rt_api.h"
+#include "rt_vec.h"
+
+namespace rthost {
+
+// src/main.cpp:138-147
+inline void throwExceptionRtAPI(int result, const char* functionName, rt_ctx* ctx = nullptr) {
+  std::string message = "RT API exception: return code " + std::to_string(result) + " (" + functionName + ")";
+  const char* detail = rt_last_error(ctx);
+  if (detail && *detail) message += ": " + std::string(detail);
+  throw std::runtime_error(message);
+}
+
+// src/main.cpp:51-63.  The reference prints reader.Error() and exit(1)s; a library cannot exit the
+// process, so the failure is thrown instead (same message).
+inline void parseFile(const tinyobj::ObjReaderConfig& reader_config, tinyobj::ObjReader& reader, const char* fileName) {
+  if (!reader.ParseFromFile(fileName, reader_config)) {
+    std::string msg = "TinyObjReader: " + (reader.Error().empty() ? std::string("failed to parse ") + fileName : reader.Error());
+    throw std::runtime_error(msg);
+  }
+  if (!reader.Warning().empty()) fprintf(stderr, "TinyObjReader: %s", reader.Warning().c_str());
+}
+
+// Everything src/main.cpp:1606-1729 builds on the host for bindings 2 and 3.
+struct SceneGeometry {
+  std::vector<float> vertexBuffer;          // objects concatenated, [px py pz nx ny nz] per vertex
+  std::vector<uint32_t> indexBuffer;        // objects concatenated, object-local indices
+  std::vector<uint32_t> primitiveCount;     // per object
+  std::vector<rt_mesh_range> ranges;        // per object offsets
+  // src/main.cpp:1872-1873
+  uint32_t orbitingObjectPrimitiveOffset() const { return ranges.size() > 1 ? (uint32_t)(ranges[1].first_index / 3) : 0; }
+  uint32_t orbitingObjectVertexOffset() const { return ranges.size() > 1 ? (uint32_t)ranges[1].first_float : 0; }
+};
+
+// src/main.cpp:1673-1682 (+ the documented rule for the reference's out-of-bounds read when an OBJ
+// has fewer `vn` than `v`: the vertex takes the vn of the LAST face corner that uses it).
+inline void interleaveVertices(const tinyobj::attrib_t& attrib, const std::vector<tinyobj::shape_t>& shapes, std::vector<float>& tmpBuffer) {
+  const std::vector<tinyobj::real_t>& vertices = attrib.vertices;
+  const std::vector<tinyobj::real_t>& normals = attrib.normals;
+  size_t vertexCount = vertices.size();
+  tmpBuffer.assign(2 * vertexCount, 0.0f);
+  const bool perVertexNormals = normals.size() == vertices.size();
+  for (size_t i = 0; i < vertexCount; i += 3) {
+    size_t offset = 2 * i, attribOffset = i;
+    tmpBuffer[offset] = vertices[attribOffset];
+    tmpBuffer[offset + 1] = vertices[attribOffset + 1];
+    tmpBuffer[offset + 2] = vertices[attribOffset + 2];
+    if (perVertexNormals) {
+      tmpBuffer[offset + 3] = normals[attribOffset];
+      tmpBuffer[offset + 4] = normals[attribOffset + 1];
+      tmpBuffer[offset + 5] = normals[attribOffset + 2];
+    }
+  }
+  if (!perVertexNormals) {
+    for (const tinyobj::shape_t& shape : shapes)
+      for (const tinyobj::index_t& index : shape.mesh.indices) {
+        if (index.normal_index < 0 || index.vertex_index < 0) continue;
+        size_t o = 6 * (size_t)index.vertex_index, n = 3 * (size_t)index.normal_index;
+        if (n + 2 >= normals.size() || o + 5 >= tmpBuffer.size()) continue;
+        tmpBuffer[o + 3] = normals[n]; tmpBuffer[o + 4] = normals[n + 1]; tmpBuffer[o + 5] = normals[n + 2];
+      }
+  }
+}
+
+// src/main.cpp:1606-1729 for an arbitrary list of OBJ files ({CENTER, ORBITING} in the reference).
+inline SceneGeometry loadScene(const std::vector<std::string>& fileNames) {
+  SceneGeometry g;
+  tinyobj::ObjReaderConfig reader_config;
+  for (const std::string& fileName : fileNames) {
+    tinyobj::ObjReader reader;
+    parseFile(reader_config, reader, fileName.c_str());
+    const tinyobj::attrib_t& attrib = reader.GetAttrib();
+    const std::vector<tinyobj::shape_t>& shapes = reader.GetShapes();
+    rt_mesh_range r{};
+    r.first_float = g.vertexBuffer.size();
+    r.first_index = g.indexBuffer.size();
+    uint32_t prims = 0;
+    for (const tinyobj::shape_t& shape : shapes) {              // src/main.cpp:1643-1650
+      prims += (uint32_t)shape.mesh.num_face_vertices.size();
+      for (const tinyobj::index_t& index : shape.mesh.indices) g.indexBuffer.push_back((uint32_t)index.vertex_index);
+    }
+    r.prim_count = prims;
+    std::vector<float> tmp;
+    interleaveVertices(attrib, shapes, tmp);
+    g.vertexBuffer.insert(g.vertexBuffer.end(), tmp.begin(), tmp.end());
+    g.primitiveCount.push_back(prims);
+    g.ranges.push_back(r);
+  }
+  return g;
+}
+
+// src/main.cpp:245-249
+inline void glmToVulkan(rtm::mat4 glmMatrix, float vulkanMatrix[12]) {
+  glmMatrix = rtm::transpose(glmMatrix);
+  memcpy(vulkanMatrix, &glmMatrix, sizeof(float) * 12);
+}
+
+// src/main.cpp:538-551
+inline rt_instance createInstance(const float transformMatrix[12], uint32_t objIndex, uint64_t mesh) {
+  rt_instance inst{};
+  memcpy(inst.transform, transformMatrix, sizeof(inst.transform));
+  inst.custom_index_and_mask = (objIndex & 0xFFFFFFu) | (0xFFu << 24);
+  inst.sbt_offset_and_flags = 0u | (0x01u << 24);  // VK_GEOMETRY_INSTANCE_TRIANGLE_FACING_CULL_DISABLE_BIT_KHR
+  inst.mesh = mesh;
+  return inst;
+}
+
+// src/main.cpp:1847-1866 initialisers
+inline rt_uniforms defaultUniforms() {
+  rt_uniforms u{};
+  const float p[4] = {0, 0, 20, 1}, r[4] = {1, 0, 0, 1}, up[4] = {0, 1, 0, 1}, f[4] = {0, 0, -1, 1};
+  memcpy(u.position, p, sizeof(p)); memcpy(u.right, r, sizeof(r)); memcpy(u.up, up, sizeof(up)); memcpy(u.forward, f, sizeof(f));
+  u.light_position[0] = u.light_position[1] = u.light_position[2] = 5.0f;
+  u.light_intensity = 1.0f;
+  u.max_bounce_count = MAX_BOUNCE_COUNT;
+  u.samples_per_pixel = SAMPLES_PER_PIXEL;
+  u.center_object_type = CENTER_MESH_TYPE;
+  u.orbiting_object_type = ORBITING_MESH_TYPE;
+  return u;
+}
+
+// src/main.cpp:1805-1808 and the per-frame animation of :2836-2844 with a caller-supplied timeParam
+// (the reference derives it from the wall clock, :2798-2799).
+struct SceneAnimation {
+  rtm::mat4 glmMatrices[2];
+  SceneAnimation() { glmMatrices[0] = rtm::mat4(1.0f); glmMatrices[1] = rtm::translate(rtm::mat4(1.0f), rtm::vec3(0.0f, 0.0f, 5.0f)); }
+  void animate(float timeParam) {
+    const double pi = 3.14159265358979323846;
+    glmMatrices[0] = glmMatrices[0] * rtm::rotate(rtm::mat4(1.0f), float(timeParam * pi * 0.0001), rtm::vec3(0.0f, 1.0f, 0.0f));
+    glmMatrices[1] = rtm::translate(rtm::rotate(rtm::translate(rtm::mat4(1.0f), rtm::vec3(0.0f, 0.0f, -5.0f)), float(timeParam * pi), rtm::vec3(0.0f, 1.0f, 0.0f)),
+                                    rtm::vec3(0.0f, 0.0f, 10.0f));
+  }
+};
+
+// Deterministic stand-in for resources/armadillo.obj, which the reference snapshot lacks
+// (.MISSING_LARGE_BLOBS): a class-I geodesic icosahedron of frequency n (20 n^2 triangles,
+// 10 n^2 + 2 vertices; n = 132 -> 348 480 triangles, the Stanford armadillo has 345 944) displaced by
+// a fixed sum of lobes, radius about 3, smooth per-vertex normals, faces written `f a//a b//b c//c`.
+void writeArmadilloStandin(const std::string& objPath, int frequency = 132);
+
+// RAII wrapper over the C ABI; every failure throws (src/main.cpp:138-147 behaviour).
+class Renderer {
+ public:
+  explicit Renderer(int device = 0) { int r = rt_create(&ctx_, device); if (r) throwExceptionRtAPI(r, "rt_create", nullptr); }
+  ~Renderer() { rt_destroy(ctx_); }
+  Renderer(const Renderer&) = delete;
+  Renderer& operator=(const Renderer&) = delete;
+  rt_ctx* handle() { return ctx_; }
+  void uploadGeometry(const SceneGeometry& g) {
+    check(rt_upload_geometry(ctx_, g.vertexBuffer.data(), g.vertexBuffer.size(), g.indexBuffer.data(), g.indexBuffer.size(), g.ranges.data(), (int)g.ranges.size()), "rt_upload_geometry");
+    for (int m = 0; m < (int)g.ranges.size(); m++) check(rt_build_blas(ctx_, m), "rt_build_blas");
+  }
+  void setInstances(const std::vector<rt_instance>& inst, bool update) { check(rt_set_instances(ctx_, inst.data(), (int)inst.size(), update ? 1 : 0), "rt_set_instances"); }
+  void setUniforms(const rt_uniforms& u) { check(rt_set_uniforms(ctx_, &u), "rt_set_uniforms"); }
+  void setSkybox(const std::vector<std::vector<uint8_t>>& faces, int w, int h) {
+    const uint8_t* p[6];
+    for (int f = 0; f < 6; f++) p[f] = faces[f].data();
+    check(rt_set_skybox(ctx_, p, w, h), "rt_set_skybox");
+  }
+  rt_stats trace(int W, int H, std::vector<float>& rgba) {
+    rgba.resize((size_t)W * H * 4);
+    rt_stats st{};
+    check(rt_trace(ctx_, W, H, rgba.data(), &st), "rt_trace");
+    return st;
+  }
+  void setTiming(bool on) { check(rt_set_timing(ctx_, on ? 1 : 0), "rt_set_timing"); }
+
+ private:
+  void check(int r, const char* fn) { if (r) throwExceptionRtAPI(r, fn, ctx_); }
+  rt_ctx* ctx_ = nullptr;
+};
+
+}  // namespace rthost
+#endif  // RT_HOST_HPP

@@ -1,0 +1,643 @@
+// rt_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+//
+// This file is a plain-C++ restatement of the reference's ray-tracing stage.  It is the
+// checker for the HIP path and the `cpu_baseline` ("port") of bench.py.  Nothing under
+// vulkan_raytracing_amd/ (the product) includes, links or calls it; only tests/,
+// __graft_entry__.smoke() and bench.py's cpu_baseline leg may.
+//
+// What it restates (reference paths relative to /root/reference):
+//   src/shader.rgen:57-59     random()            -> orc::jitter_hash
+//   src/shader.rgen:61-186    main()              -> orc::shade_sample / render rows
+//   src/shader.rchit:50-96    main()              -> orc::closest_hit_attributes
+//   src/shader.rmiss:11       objectIndex = -1    -> Hit::inst < 0
+//   src/shader_shadow.rmiss:6 isShadow = false    -> !occluded()
+//   src/main.cpp:245-249      glmToVulkan (row-major 3x4 object->world)
+//   src/main.cpp:538-551      instance record (customIndex, mask, cull-disable)
+//   src/main.cpp:1847-1873    UniformStructure (104 bytes)
+//   src/main.cpp:2064-2071, 2116-2130, 2393-2406  cube map: layer order, RGBA8 UNORM, LINEAR, CLAMP_TO_EDGE
+// and the Vulkan-spec semantics of traceRayEXT that the driver implements for
+// src/shader.rgen:86-87 and :111-112 (the reference has no source for these):
+//   closest hit with tmin < t < tmax, no culling, opaque; any-hit terminate for shadow rays;
+//   ray transformed per instance by inverse(objectToWorld) without renormalising (t preserved).
+//
+// PARITY STATUS: "parity unpinned" for images — the reference holds no tests, golden images or
+// runnable CPU path for this stage.  What IS pinned by reference artefacts:
+//   * every numeric shader constant, against the OpConstant words of the reference's own
+//     shaders/*.spv (tests/golden/spv_constants.json);
+//   * the geometry ingest (a1-a4), against the reference's vendored tiny_obj_loader.h compiled
+//     in place (oracle/_ref, tests/golden/ingest_*.json);
+//   * the analytic known answers of SURVEY.md Appendix B.
+//
+// CANONICAL ARITHMETIC.  GLSL leaves the precision of sin/pow/normalize and FMA contraction to
+// the implementation, so no two Vulkan drivers produce identical bits.  The oracle fixes ONE
+// definition built only from IEEE-754 binary32/binary64 +,-,*,/,sqrt and explicit fma, which
+// the HIP kernels repeat operation for operation (file compiled with -ffp-contract=off):
+//   dot3(a,b)    = fma(a.z,b.z, fma(a.y,b.y, a.x*b.x))
+//   cross(a,b).x = fma(a.y,b.z, -(a.z*b.y))  (cyclic)
+//   length(v)    = sqrt(dot3(v,v));  normalize(v) = v * (1/length(v))
+//   reflect(I,N) = fma(-(2*dot3(N,I)), N, I)
+//   pow(x,100)   = ((x^64 * x^32) * x^4) by repeated squaring;  pow(0.9,i) = i-fold product
+//   sin(x)       = canon_sin: binary64 Cody-Waite reduction + fdlibm kernel polynomials,
+//                  rounded once to binary32
+//   closest hit  = minimum t; ties broken by smaller (instance index, primitive index)
+//
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+namespace orc {
+
+struct V3 { float x, y, z; };
+static inline V3 mk(float x, float y, float z) { return V3{x, y, z}; }
+static inline V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator*(V3 a, float s) { return mk(a.x * s, a.y * s, a.z * s); }
+static inline V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+static inline float dot3(V3 a, V3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline V3 cross(V3 a, V3 b) {
+  return mk(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline float length3(V3 v) { return sqrtf(dot3(v, v)); }
+static inline V3 normalize3(V3 v) { float inv = 1.0f / length3(v); return v * inv; }
+static inline V3 fma3(float s, V3 a, V3 b) { return mk(fmaf(s, a.x, b.x), fmaf(s, a.y, b.y), fmaf(s, a.z, b.z)); }
+static inline V3 reflect3(V3 I, V3 N) { float k = 2.0f * dot3(N, I); return fma3(-k, N, I); }
+
+// ---------------------------------------------------------------------------------------------
+// canon_sin: binary64 sine from IEEE basic operations only (bit-reproducible on any IEEE machine).
+// Reduction x = k*(pi/2) + r by two fma steps (valid for |x| < 2^20*pi/2, the hash argument stays
+// below ~3e5), then the classic fdlibm __kernel_sin/__kernel_cos minimax polynomials on |r|<=pi/4.
+static inline double poly_sin(double r) {
+  const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03,
+               S3 = -1.98412698298579493134e-04, S4 = 2.75573137070700676789e-06,
+               S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+  double z = r * r;
+  double p = fma(z, S6, S5);
+  p = fma(z, p, S4);
+  p = fma(z, p, S3);
+  p = fma(z, p, S2);
+  p = fma(z, p, S1);
+  return fma(r * z, p, r);
+}
+static inline double poly_cos(double r) {
+  const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03,
+               C3 = 2.48015872894767294178e-05, C4 = -2.75573143513906633035e-07,
+               C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+  double z = r * r;
+  double p = fma(z, C6, C5);
+  p = fma(z, p, C4);
+  p = fma(z, p, C3);
+  p = fma(z, p, C2);
+  p = fma(z, p, C1);
+  return fma(z * z, p, fma(z, -0.5, 1.0));
+}
+static inline double canon_sin(double x) {
+  const double TWO_OVER_PI = 6.36619772367581382433e-01;
+  const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17;
+  double k = nearbyint(x * TWO_OVER_PI);  // round-half-even; |k| < 2^20
+  double r = fma(-k, PIO2_HI, x);
+  r = fma(-k, PIO2_LO, r);
+  long long q = (long long)k & 3;
+  switch (q) {
+    case 0: return poly_sin(r);
+    case 1: return poly_cos(r);
+    case 2: return -poly_sin(r);
+    default: return -poly_cos(r);
+  }
+}
+
+// src/shader.rgen:57-59.  fract(sin(dot(uv, vec2(12.9898, 78.233)) + 1113.1*seed) * 43758.5453).
+// Every step rounded to binary32, no contraction (SURVEY.md §8c trap 2).
+static inline float jitter_hash(float px, float py, float seed) {
+  float d = px * 12.9898f + py * 78.233f;   // -ffp-contract=off: mul, mul, add
+  float a = d + 1113.1f * seed;
+  float s = (float)canon_sin((double)a);
+  float x = s * 43758.5453f;
+  return x - floorf(x);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Scene data (mirrors the descriptor set of src/main.cpp:1305-1335: b1 UBO, b2 index, b3 vertex,
+// b5 cube; b0 TLAS = instances + per-mesh BVH).
+struct Uniforms {  // src/main.cpp:1847-1866, src/shader.rgen:22-46 — 104 bytes
+  float position[4], right[4], up[4], forward[4];
+  float lightPosition[3];
+  float lightIntensity;
+  uint32_t maxBounceCount, samplesPerPixel, centerObjectType, orbitingObjectType;
+  uint32_t orbitingObjectPrimitiveOffset, orbitingObjectVertexOffset;
+};
+static_assert(sizeof(Uniforms) == 104, "UniformStructure must be 104 bytes");
+
+struct MeshRange { uint64_t first_float, first_index; uint32_t prim_count, pad; };
+
+struct InstanceIn {  // 64-byte mirror of VkAccelerationStructureInstanceKHR (src/main.cpp:538-551)
+  float transform[12];           // row-major 3x4 object->world (glmToVulkan, src/main.cpp:245-249)
+  uint32_t custom_index_and_mask;  // customIndex:24 | mask:8
+  uint32_t sbt_and_flags;          // sbtOffset:24 | flags:8
+  uint64_t mesh;                   // stands in for accelerationStructureReference
+};
+static_assert(sizeof(InstanceIn) == 64, "instance record must be 64 bytes");
+
+struct Hit { float t, u, v; int32_t prim, inst; };  // inst < 0: miss
+
+struct BNode { float lo[3], hi[3]; int32_t left, right; uint32_t first, count; };  // count>0: leaf
+
+struct Mesh {
+  uint64_t first_float = 0, first_index = 0;
+  uint32_t prim_count = 0;
+  std::vector<BNode> nodes;
+  std::vector<uint32_t> order;  // leaf-order -> primitive id
+};
+
+struct Instance {
+  float o2w[12], w2o[12];
+  int32_t custom_index;
+  uint32_t mask;
+  uint32_t mesh;
+};
+
+struct Scene {
+  std::vector<float> verts;
+  std::vector<uint32_t> idx;
+  std::vector<Mesh> meshes;
+  std::vector<Instance> inst;
+  Uniforms uni;
+  std::vector<uint8_t> sky;  // 6 layers RGBA8
+  int sky_w = 0, sky_h = 0;
+  bool has_uni = false;
+};
+
+// inverse of a row-major 3x4 affine transform, evaluated in binary64 and rounded once
+// (gl_WorldToObjectEXT = inverse(gl_ObjectToWorldEXT)).
+static void invert_affine(const float m[12], float out[12]) {
+  double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+  double tx = m[3], ty = m[7], tz = m[11];
+  double c00 = e * i - f * h, c01 = c * h - b * i, c02 = b * f - c * e;
+  double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
+  double c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
+  double det = a * c00 + b * c10 + c * c20;
+  double r = 1.0 / det;
+  double n[9] = {c00 * r, c01 * r, c02 * r, c10 * r, c11 * r, c12 * r, c20 * r, c21 * r, c22 * r};
+  out[0] = (float)n[0]; out[1] = (float)n[1]; out[2] = (float)n[2];
+  out[4] = (float)n[3]; out[5] = (float)n[4]; out[6] = (float)n[5];
+  out[8] = (float)n[6]; out[9] = (float)n[7]; out[10] = (float)n[8];
+  out[3] = (float)(-(n[0] * tx + n[1] * ty + n[2] * tz));
+  out[7] = (float)(-(n[3] * tx + n[4] * ty + n[5] * tz));
+  out[11] = (float)(-(n[6] * tx + n[7] * ty + n[8] * tz));
+}
+
+static inline V3 xform_point(const float m[12], V3 p) {
+  return mk(fmaf(m[2], p.z, fmaf(m[1], p.y, m[0] * p.x)) + m[3],
+            fmaf(m[6], p.z, fmaf(m[5], p.y, m[4] * p.x)) + m[7],
+            fmaf(m[10], p.z, fmaf(m[9], p.y, m[8] * p.x)) + m[11]);
+}
+static inline V3 xform_vec(const float m[12], V3 p) {
+  return mk(fmaf(m[2], p.z, fmaf(m[1], p.y, m[0] * p.x)),
+            fmaf(m[6], p.z, fmaf(m[5], p.y, m[4] * p.x)),
+            fmaf(m[10], p.z, fmaf(m[9], p.y, m[8] * p.x)));
+}
+// vec3 * mat4x3 (src/shader.rchit:94): component j = dot(n, column j of the 3x3 part).
+static inline V3 xform_normal(const float w2o[12], V3 n) {
+  return mk(fmaf(w2o[8], n.z, fmaf(w2o[4], n.y, w2o[0] * n.x)),
+            fmaf(w2o[9], n.z, fmaf(w2o[5], n.y, w2o[1] * n.x)),
+            fmaf(w2o[10], n.z, fmaf(w2o[6], n.y, w2o[2] * n.x)));
+}
+
+static inline V3 vert_pos(const Scene& s, const Mesh& m, uint32_t vi) {
+  const float* p = &s.verts[m.first_float + 6ull * vi];
+  return mk(p[0], p[1], p[2]);
+}
+static inline V3 vert_nrm(const Scene& s, const Mesh& m, uint32_t vi) {
+  const float* p = &s.verts[m.first_float + 6ull * vi];
+  return mk(p[3], p[4], p[5]);
+}
+
+// Möller–Trumbore, two-sided (VK_GEOMETRY_INSTANCE_TRIANGLE_FACING_CULL_DISABLE, src/main.cpp:548).
+// Division-free rejection on sign-folded numerators, one IEEE reciprocal for an accepted candidate.
+// Accept iff tmin < t < tmax (exclusive, Vulkan ray-traversal chapter).
+static inline bool tri_test(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float tmin, float tmax, float& t, float& u, float& v) {
+  V3 p = cross(d, e2);
+  float det = dot3(e1, p);
+  V3 s = o - v0;
+  float un = dot3(s, p);
+  V3 q = cross(s, e1);
+  float vn = dot3(d, q);
+  float tn = dot3(e2, q);
+  float da = fabsf(det);
+  if (det < 0.0f) { un = -un; vn = -vn; tn = -tn; }
+  if (!(un >= 0.0f) || !(vn >= 0.0f) || !(un + vn <= da) || !(da > 0.0f)) return false;
+  float inv = 1.0f / da;
+  float tt = tn * inv;
+  if (!(tt > tmin) || !(tt < tmax)) return false;
+  t = tt; u = un * inv; v = vn * inv;
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Oracle-private BVH (binned SAH, leaves <= 4).  Independent of the product's builder; its only
+// contract is conservativeness, checked against brute force in tests/test_oracle.py.
+struct BuildTri { float lo[3], hi[3], c[3]; uint32_t id; };
+
+static void build_mesh_bvh(const Scene& s, Mesh& m) {
+  uint32_t n = m.prim_count;
+  std::vector<BuildTri> tris(n);
+  for (uint32_t i = 0; i < n; i++) {
+    BuildTri& t = tris[i];
+    t.id = i;
+    for (int k = 0; k < 3; k++) { t.lo[k] = 3.0e38f; t.hi[k] = -3.0e38f; }
+    for (int c = 0; c < 3; c++) {
+      V3 p = vert_pos(s, m, s.idx[m.first_index + 3ull * i + c]);
+      float pv[3] = {p.x, p.y, p.z};
+      for (int k = 0; k < 3; k++) { t.lo[k] = std::min(t.lo[k], pv[k]); t.hi[k] = std::max(t.hi[k], pv[k]); }
+    }
+    for (int k = 0; k < 3; k++) t.c[k] = 0.5f * (t.lo[k] + t.hi[k]);
+  }
+  m.nodes.clear();
+  m.nodes.reserve(2 * n / 2 + 4);
+  struct Job { uint32_t node, first, count, depth; };
+  std::vector<Job> stack;
+  m.nodes.push_back(BNode{});
+  stack.push_back({0, 0, n, 0});
+  const int NB = 16;
+  while (!stack.empty()) {
+    Job j = stack.back(); stack.pop_back();
+    float lo[3] = {3e38f, 3e38f, 3e38f}, hi[3] = {-3e38f, -3e38f, -3e38f};
+    float clo[3] = {3e38f, 3e38f, 3e38f}, chi[3] = {-3e38f, -3e38f, -3e38f};
+    for (uint32_t i = j.first; i < j.first + j.count; i++)
+      for (int k = 0; k < 3; k++) {
+        lo[k] = std::min(lo[k], tris[i].lo[k]); hi[k] = std::max(hi[k], tris[i].hi[k]);
+        clo[k] = std::min(clo[k], tris[i].c[k]); chi[k] = std::max(chi[k], tris[i].c[k]);
+      }
+    BNode nd{};
+    for (int k = 0; k < 3; k++) { nd.lo[k] = lo[k]; nd.hi[k] = hi[k]; }
+    nd.first = j.first; nd.count = 0; nd.left = nd.right = -1;
+    if (j.count <= 4) { nd.count = j.count; m.nodes[j.node] = nd; continue; }
+    int axis = 0;
+    for (int k = 1; k < 3; k++) if (chi[k] - clo[k] > chi[axis] - clo[axis]) axis = k;
+    uint32_t mid = j.first + j.count / 2;
+    float ext = chi[axis] - clo[axis];
+    bool split_done = false;
+    if (ext > 0.0f && j.depth < 48) {
+      // binned SAH (median split below depth 48 keeps the traversal stack bounded) on the widest centroid axis
+      uint32_t cnt[NB] = {0};
+      float blo[NB][3], bhi[NB][3];
+      for (int b = 0; b < NB; b++) for (int k = 0; k < 3; k++) { blo[b][k] = 3e38f; bhi[b][k] = -3e38f; }
+      float scale = (float)NB / ext;
+      auto bin_of = [&](const BuildTri& t) { int b = (int)((t.c[axis] - clo[axis]) * scale); return b < 0 ? 0 : (b >= NB ? NB - 1 : b); };
+      for (uint32_t i = j.first; i < j.first + j.count; i++) {
+        int b = bin_of(tris[i]); cnt[b]++;
+        for (int k = 0; k < 3; k++) { blo[b][k] = std::min(blo[b][k], tris[i].lo[k]); bhi[b][k] = std::max(bhi[b][k], tris[i].hi[k]); }
+      }
+      auto area = [](const float* l, const float* h) { float dx = h[0] - l[0], dy = h[1] - l[1], dz = h[2] - l[2]; return dx * dy + dy * dz + dz * dx; };
+      float la[NB], ra[NB]; uint32_t lc[NB], rc[NB];
+      float l[3] = {3e38f, 3e38f, 3e38f}, h[3] = {-3e38f, -3e38f, -3e38f}; uint32_t c = 0;
+      for (int b = 0; b < NB; b++) { c += cnt[b]; for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], blo[b][k]); h[k] = std::max(h[k], bhi[b][k]); } la[b] = c ? area(l, h) : 0.f; lc[b] = c; }
+      for (int k = 0; k < 3; k++) { l[k] = 3e38f; h[k] = -3e38f; } c = 0;
+      for (int b = NB - 1; b >= 0; b--) { c += cnt[b]; for (int k = 0; k < 3; k++) { l[k] = std::min(l[k], blo[b][k]); h[k] = std::max(h[k], bhi[b][k]); } ra[b] = c ? area(l, h) : 0.f; rc[b] = c; }
+      float best = 3e38f; int bb = -1;
+      for (int b = 0; b < NB - 1; b++) {
+        if (lc[b] == 0 || rc[b + 1] == 0) continue;
+        float cost = la[b] * lc[b] + ra[b + 1] * rc[b + 1];
+        if (cost < best) { best = cost; bb = b; }
+      }
+      if (bb >= 0) {
+        auto it = std::partition(tris.begin() + j.first, tris.begin() + j.first + j.count, [&](const BuildTri& t) { return bin_of(t) <= bb; });
+        mid = (uint32_t)(it - tris.begin());
+        split_done = (mid > j.first && mid < j.first + j.count);
+      }
+    }
+    if (!split_done) {
+      mid = j.first + j.count / 2;
+      std::nth_element(tris.begin() + j.first, tris.begin() + mid, tris.begin() + j.first + j.count,
+                       [&](const BuildTri& a, const BuildTri& b) { return a.c[axis] < b.c[axis]; });
+    }
+    nd.left = (int32_t)m.nodes.size(); nd.right = nd.left + 1;
+    m.nodes[j.node] = nd;
+    m.nodes.push_back(BNode{}); m.nodes.push_back(BNode{});
+    stack.push_back({(uint32_t)nd.right, mid, j.first + j.count - mid, j.depth + 1});
+    stack.push_back({(uint32_t)nd.left, j.first, mid - j.first, j.depth + 1});
+  }
+  m.order.resize(n);
+  for (uint32_t i = 0; i < n; i++) m.order[i] = tris[i].id;
+}
+
+// Conservative slab test: generous relative + absolute slack; only ever widens the accepted set.
+static inline bool box_test(const BNode& b, V3 o, V3 id, float tmin, float tmax) {
+  float t0x = (b.lo[0] - o.x) * id.x, t1x = (b.hi[0] - o.x) * id.x;
+  float t0y = (b.lo[1] - o.y) * id.y, t1y = (b.hi[1] - o.y) * id.y;
+  float t0z = (b.lo[2] - o.z) * id.z, t1z = (b.hi[2] - o.z) * id.z;
+  float tn = std::max(std::max(std::min(t0x, t1x), std::min(t0y, t1y)), std::max(std::min(t0z, t1z), tmin));
+  float tf = std::min(std::min(std::max(t0x, t1x), std::max(t0y, t1y)), std::min(std::max(t0z, t1z), tmax));
+  return tn <= tf * 1.0001f + 1e-5f;
+}
+static inline float safe_inv(float d) {
+  const float eps = 1e-20f;
+  if (fabsf(d) < eps) d = (std::signbit(d) ? -eps : eps);
+  return 1.0f / d;
+}
+
+struct Counters { uint64_t nodes = 0, tris = 0; };
+
+// closest (any_hit=0) or first-accepted (any_hit=1) hit of one ray against the two-level scene.
+static bool trace(const Scene& s, V3 o, V3 d, float tmin, float tmax, bool any_hit, bool use_bvh, Hit& best, Counters* cnt) {
+  best.t = tmax; best.u = best.v = 0.f; best.prim = -1; best.inst = -1;
+  bool found = false;
+  for (size_t ii = 0; ii < s.inst.size(); ii++) {
+    const Instance& in = s.inst[ii];
+    if ((in.mask & 0xFFu) == 0) continue;  // ray mask 0xFF (src/shader.rgen:86)
+    const Mesh& m = s.meshes[in.mesh];
+    V3 oo = xform_point(in.w2o, o), od = xform_vec(in.w2o, d);
+    auto consider = [&](uint32_t prim) {
+      const uint32_t* ix = &s.idx[m.first_index + 3ull * prim];
+      V3 v0 = vert_pos(s, m, ix[0]), v1 = vert_pos(s, m, ix[1]), v2 = vert_pos(s, m, ix[2]);
+      float t, u, v;
+      if (cnt) cnt->tris++;
+      // tie rule needs candidates at t == best.t too, so test against the open interval above best.t
+      if (!tri_test(oo, od, v0, v1 - v0, v2 - v0, tmin, tmax, t, u, v)) return false;
+      bool better = !found || t < best.t || (t == best.t && ((int32_t)ii < best.inst || ((int32_t)ii == best.inst && (int32_t)prim < best.prim)));
+      if (better) { best.t = t; best.u = u; best.v = v; best.prim = (int32_t)prim; best.inst = (int32_t)ii; found = true; }
+      return true;
+    };
+    if (!use_bvh) {
+      for (uint32_t p = 0; p < m.prim_count; p++) { consider(p); if (any_hit && found) return true; }
+      continue;
+    }
+    if (m.nodes.empty()) continue;
+    V3 id = mk(safe_inv(od.x), safe_inv(od.y), safe_inv(od.z));
+    int32_t stack[128]; int sp = 0; stack[sp++] = 0;
+    while (sp) {
+      const BNode& nd = m.nodes[stack[--sp]];
+      if (cnt) cnt->nodes++;
+      if (!box_test(nd, oo, id, tmin, found ? best.t : tmax)) continue;
+      if (nd.count) {
+        for (uint32_t k = 0; k < nd.count; k++) { consider(m.order[nd.first + k]); if (any_hit && found) return true; }
+      } else { stack[sp++] = nd.right; stack[sp++] = nd.left; }
+    }
+  }
+  return found;
+}
+
+// src/shader.rchit:50-96.
+static void closest_hit_attributes(const Scene& s, const Hit& h, V3& P, V3& N, int& objectIndex) {
+  const Instance& in = s.inst[h.inst];
+  const Mesh& m = s.meshes[in.mesh];
+  const uint32_t* ix = &s.idx[m.first_index + 3ull * (uint32_t)h.prim];
+  float bx = (1.0f - h.u) - h.v, by = h.u, bz = h.v;
+  V3 pa = vert_pos(s, m, ix[0]), pb = vert_pos(s, m, ix[1]), pc = vert_pos(s, m, ix[2]);
+  V3 na = vert_nrm(s, m, ix[0]), nb = vert_nrm(s, m, ix[1]), nc = vert_nrm(s, m, ix[2]);
+  V3 pos = fma3(bz, pc, fma3(by, pb, pa * bx));
+  V3 nrm = fma3(bz, nc, fma3(by, nb, na * bx));
+  P = xform_point(in.o2w, pos);
+  N = normalize3(xform_normal(in.w2o, nrm));
+  objectIndex = in.custom_index;
+}
+
+// Cube-map lookup, VK_FILTER_LINEAR, CLAMP_TO_EDGE per face (seam filtering
+// across faces is NOT reproduced — differs from Vulkan only within half a texel of a face edge).
+static V3 sample_sky(const Scene& s, V3 r) {
+  if (s.sky_w == 0) return mk(0.f, 0.f, 0.f);
+  float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
+  int layer; float sc, tc, ma;
+  if (az >= ax && az >= ay) { ma = az; if (r.z >= 0.f) { layer = 4; sc = r.x; tc = -r.y; } else { layer = 5; sc = -r.x; tc = -r.y; } }
+  else if (ay >= ax)        { ma = ay; if (r.y >= 0.f) { layer = 2; sc = r.x; tc = r.z; } else { layer = 3; sc = r.x; tc = -r.z; } }
+  else                      { ma = ax; if (r.x >= 0.f) { layer = 0; sc = -r.z; tc = -r.y; } else { layer = 1; sc = r.z; tc = -r.y; } }
+  float fs = 0.5f * (sc / ma + 1.0f), ft = 0.5f * (tc / ma + 1.0f);
+  float u = fs * (float)s.sky_w - 0.5f, v = ft * (float)s.sky_h - 0.5f;
+  float fu0 = floorf(u), fv0 = floorf(v);
+  float wu = u - fu0, wv = v - fv0;
+  int x0 = (int)fu0, y0 = (int)fv0, x1 = x0 + 1, y1 = y0 + 1;
+  auto cl = [](int a, int n) { return a < 0 ? 0 : (a >= n ? n - 1 : a); };
+  x0 = cl(x0, s.sky_w); x1 = cl(x1, s.sky_w); y0 = cl(y0, s.sky_h); y1 = cl(y1, s.sky_h);
+  const uint8_t* base = s.sky.data() + (size_t)layer * s.sky_w * s.sky_h * 4;
+  const uint8_t* c00 = base + ((size_t)y0 * s.sky_w + x0) * 4;
+  const uint8_t* c10 = base + ((size_t)y0 * s.sky_w + x1) * 4;
+  const uint8_t* c01 = base + ((size_t)y1 * s.sky_w + x0) * 4;
+  const uint8_t* c11 = base + ((size_t)y1 * s.sky_w + x1) * 4;
+  float out[3];
+  float iu = 1.0f - wu, iv = 1.0f - wv;
+  for (int k = 0; k < 3; k++) {
+    float a = fmaf((float)c10[k], wu, (float)c00[k] * iu);
+    float b = fmaf((float)c11[k], wu, (float)c01[k] * iu);
+    out[k] = fmaf(b, wv, a * iv) / 255.0f;  // R8G8B8A8_UNORM, no sRGB decode (src/main.cpp:2124)
+  }
+  return mk(out[0], out[1], out[2]);
+}
+
+static inline float pow100(float x) {
+  float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
+  return (x64 * x32) * x4;
+}
+
+struct RayCounts { uint64_t primary = 0, secondary = 0, shadow = 0; };
+
+// One sample of one pixel: src/shader.rgen:70-181.
+static V3 shade_sample(const Scene& s, uint32_t px, uint32_t py, uint32_t W, uint32_t H, uint32_t i, bool use_bvh, RayCounts& rc, Counters* cnt) {
+  const Uniforms& U = s.uni;
+  uint32_t samples = U.samplesPerPixel;
+  float fx = (float)px, fy = (float)py;
+  float seed0 = (float)(samples + i);       // uint + int -> uint -> float
+  float seed1 = (float)(samples + i) + 0.5f;
+  float ux = fx + jitter_hash(fx, fy, seed0);
+  float uy = fy + jitter_hash(fx, fy, seed1);
+  ux = ux / (float)W; uy = uy / (float)H;
+  ux = fmaf(ux, 2.0f, -1.0f); uy = -fmaf(uy, 2.0f, -1.0f);
+  V3 o = mk(U.position[0], U.position[1], U.position[2]);
+  V3 right = mk(U.right[0], U.right[1], U.right[2]), up = mk(U.up[0], U.up[1], U.up[2]), fwd = mk(U.forward[0], U.forward[1], U.forward[2]);
+  V3 d = normalize3(fma3(2.5f, fwd, fma3(uy, up, right * ux)));
+  // Iamb*ka as folded by glslang in shaders/shader.rgen.spv (0x3da3d70a, 0x3e75c28f, 0x3da3d70a)
+  const V3 ambient = mk(0.08f, 0.24f, 0.08f);
+  V3 tmp = ambient;
+  for (uint32_t j = 0; j <= U.maxBounceCount; j++) {
+    Hit h;
+    if (j == 0) rc.primary++; else rc.secondary++;
+    bool hit = trace(s, o, d, 0.001f, 10000.0f, false, use_bvh, h, cnt);
+    if (!hit) { tmp = sample_sky(s, mk(d.x, d.y, -d.z)); break; }
+    V3 P, N; int objectIndex;
+    closest_hit_attributes(s, h, P, N, objectIndex);
+    uint32_t type = objectIndex == 0 ? U.centerObjectType : U.orbitingObjectType;
+    if (type == 0) {
+      if (dot3(d, N) >= 0.0f) break;
+      V3 so = fma3(0.01f, N, P);
+      V3 toL = mk(U.lightPosition[0], U.lightPosition[1], U.lightPosition[2]) - P;
+      float dist = length3(toL);
+      V3 L = toL * (1.0f / dist);
+      Hit sh;
+      rc.shadow++;
+      bool occ = trace(s, so, L, 0.001f, dist, true, use_bvh, sh, cnt);
+      if (!occ) {
+        V3 Hh = normalize3(L + neg(d));
+        float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
+        float dl = std::max(0.0f, NdotL), sp = pow100(std::max(0.0f, NdotH));
+        float w = 1.0f; for (uint32_t k = 0; k < i; k++) w = w * 0.9f;  // pow(0.9, float(i)), i = SAMPLE index
+        float I = U.lightIntensity;
+        V3 diff = mk((I * 0.2f) * dl, (I * 1.0f) * dl, (I * 0.2f) * dl);
+        V3 spec = mk((I * 0.8f) * sp, (I * 0.8f) * sp, (I * 0.8f) * sp);
+        tmp = fma3(w, diff + spec, tmp);
+      }
+      break;
+    } else if (type == 1) {
+      o = fma3(0.01f, N, P);
+      d = reflect3(d, N);
+    } else if (type == 2) {
+      float ndoti = dot3(d, N);
+      bool outwards = ndoti > 0.0f;
+      if (outwards) { N = neg(N); ndoti = -ndoti; }
+      float ratio = outwards ? 1.52f : (1.0f / 1.52f);
+      float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
+      if (k < 0.0f) { d = reflect3(d, N); o = fma3(0.01f, N, P); }
+      else {
+        float c = fmaf(ratio, ndoti, sqrtf(k));
+        V3 R = fma3(-c, N, d * ratio);
+        d = normalize3(R);
+        o = fma3(-0.01f, N, P);
+      }
+    }
+  }
+  return tmp;
+}
+
+static void render_rows(const Scene& s, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, float* out, bool use_bvh, RayCounts& rc, Counters* cnt) {
+  uint32_t spp = s.uni.samplesPerPixel;
+  for (uint32_t y = y0; y < y1; y++)
+    for (uint32_t x = 0; x < W; x++) {
+      float c[4] = {0, 0, 0, 0};
+      for (uint32_t i = 0; i < spp; i++) {
+        V3 t = shade_sample(s, x, y, W, H, i, use_bvh, rc, cnt);
+        c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += 1.0f;
+      }
+      float n = (float)spp;
+      float* p = out + ((size_t)y * W + x) * 4;
+      p[0] = c[0] / n; p[1] = c[1] / n; p[2] = c[2] / n; p[3] = c[3] / n;
+    }
+}
+
+}  // namespace orc
+
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+using namespace orc;
+
+void* orc_create() { return new Scene(); }
+void orc_destroy(void* p) { delete (Scene*)p; }
+
+int orc_set_geometry(void* p, const float* verts, uint64_t n_floats, const uint32_t* idx, uint64_t n_idx, const MeshRange* ranges, int n_meshes) {
+  Scene& s = *(Scene*)p;
+  s.verts.assign(verts, verts + n_floats);
+  s.idx.assign(idx, idx + n_idx);
+  s.meshes.clear();
+  for (int i = 0; i < n_meshes; i++) {
+    Mesh m; m.first_float = ranges[i].first_float; m.first_index = ranges[i].first_index; m.prim_count = ranges[i].prim_count;
+    if (m.first_index + 3ull * m.prim_count > n_idx) return 1;
+    s.meshes.push_back(std::move(m));
+  }
+  for (auto& m : s.meshes) build_mesh_bvh(s, m);
+  return 0;
+}
+
+int orc_set_instances(void* p, const InstanceIn* in, int n) {
+  Scene& s = *(Scene*)p;
+  s.inst.clear();
+  for (int i = 0; i < n; i++) {
+    Instance I;
+    memcpy(I.o2w, in[i].transform, sizeof(I.o2w));
+    invert_affine(I.o2w, I.w2o);
+    I.custom_index = (int32_t)(in[i].custom_index_and_mask & 0xFFFFFFu);
+    I.mask = in[i].custom_index_and_mask >> 24;
+    I.mesh = (uint32_t)in[i].mesh;
+    if (I.mesh >= s.meshes.size()) return 1;
+    s.inst.push_back(I);
+  }
+  return 0;
+}
+
+int orc_set_uniforms(void* p, const Uniforms* u) { Scene& s = *(Scene*)p; s.uni = *u; s.has_uni = true; return 0; }
+
+int orc_set_skybox(void* p, const uint8_t* const* faces, int w, int h) {
+  Scene& s = *(Scene*)p;
+  s.sky_w = w; s.sky_h = h;
+  s.sky.resize((size_t)6 * w * h * 4);
+  for (int f = 0; f < 6; f++) memcpy(s.sky.data() + (size_t)f * w * h * 4, faces[f], (size_t)w * h * 4);
+  return 0;
+}
+
+// rays: 8 floats each (o.xyz, tmin, d.xyz, tmax).  out: n Hit records.
+int orc_intersect(void* p, uint64_t n, const float* rays, int any_hit, int use_bvh, Hit* out, uint64_t* visit_counts /*[2] or null*/) {
+  Scene& s = *(Scene*)p;
+  Counters c;
+  for (uint64_t i = 0; i < n; i++) {
+    const float* r = rays + 8 * i;
+    Hit h;
+    bool f = trace(s, mk(r[0], r[1], r[2]), mk(r[4], r[5], r[6]), r[3], r[7], any_hit != 0, use_bvh != 0, h, visit_counts ? &c : nullptr);
+    if (!f) { h.t = r[7]; h.u = h.v = 0.f; h.prim = -1; h.inst = -1; }
+    out[i] = h;
+  }
+  if (visit_counts) { visit_counts[0] = c.nodes; visit_counts[1] = c.tris; }
+  return 0;
+}
+
+// hit attributes for record-level checks of the rchit restatement: out = P.xyz, N.xyz, objectIndex
+int orc_hit_attributes(void* p, uint64_t n, const Hit* hits, float* out7) {
+  Scene& s = *(Scene*)p;
+  for (uint64_t i = 0; i < n; i++) {
+    float* o = out7 + 7 * i;
+    if (hits[i].inst < 0) { for (int k = 0; k < 6; k++) o[k] = 0.f; o[6] = -1.f; continue; }
+    V3 P, N; int oi;
+    closest_hit_attributes(s, hits[i], P, N, oi);
+    o[0] = P.x; o[1] = P.y; o[2] = P.z; o[3] = N.x; o[4] = N.y; o[5] = N.z; o[6] = (float)oi;
+  }
+  return 0;
+}
+
+// Renders rows [y0,y1) of a W x H frame into out (full-frame RGBA32F buffer, row 0 = top).
+// ray_counts[3] = primary, secondary, shadow (added to).  threads<=0: hardware_concurrency.
+int orc_render(void* p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, float* out, int threads, int use_bvh, uint64_t* ray_counts) {
+  Scene& s = *(Scene*)p;
+  if (!s.has_uni) return 1;
+  if (threads <= 0) threads = (int)std::thread::hardware_concurrency();
+  if (threads < 1) threads = 1;
+  std::atomic<uint32_t> next(y0);
+  std::vector<RayCounts> rcs(threads);
+  auto work = [&](int tid) {
+    for (;;) {
+      uint32_t y = next.fetch_add(4);
+      if (y >= y1) break;
+      render_rows(s, W, H, y, std::min(y + 4, y1), out, use_bvh != 0, rcs[tid], nullptr);
+    }
+  };
+  if (threads == 1) work(0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < threads; t++) th.emplace_back(work, t);
+    for (auto& t : th) t.join();
+  }
+  if (ray_counts) for (auto& r : rcs) { ray_counts[0] += r.primary; ray_counts[1] += r.secondary; ray_counts[2] += r.shadow; }
+  return 0;
+}
+
+float orc_jitter(float px, float py, float seed) { return jitter_hash(px, py, seed); }
+double orc_sin(double x) { return canon_sin(x); }
+float orc_pow100(float x) { return pow100(x); }
+void orc_invert_affine(const float* m, float* out) { invert_affine(m, out); }
+void orc_sample_sky(void* p, const float* dir, float* rgb) { V3 c = sample_sky(*(Scene*)p, mk(dir[0], dir[1], dir[2])); rgb[0] = c.x; rgb[1] = c.y; rgb[2] = c.z; }
+int orc_tri_test(const float* o, const float* d, const float* v0, const float* v1, const float* v2, float tmin, float tmax, float* tuv) {
+  V3 a = mk(v0[0], v0[1], v0[2]), b = mk(v1[0], v1[1], v1[2]), c = mk(v2[0], v2[1], v2[2]);
+  return tri_test(mk(o[0], o[1], o[2]), mk(d[0], d[1], d[2]), a, b - a, c - a, tmin, tmax, tuv[0], tuv[1], tuv[2]) ? 1 : 0;
+}
+void orc_primary_ray(void* p, uint32_t px, uint32_t py, uint32_t W, uint32_t H, uint32_t i, float* od6);
+}
+
+void orc_primary_ray(void* p, uint32_t px, uint32_t py, uint32_t W, uint32_t H, uint32_t i, float* od6) {
+  using namespace orc;
+  Scene& s = *(Scene*)p; const Uniforms& U = s.uni;
+  float fx = (float)px, fy = (float)py;
+  float seed0 = (float)(U.samplesPerPixel + i), seed1 = seed0 + 0.5f;
+  float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)W, uy = (fy + jitter_hash(fx, fy, seed1)) / (float)H;
+  ux = fmaf(ux, 2.0f, -1.0f); uy = -fmaf(uy, 2.0f, -1.0f);
+  V3 right = mk(U.right[0], U.right[1], U.right[2]), up = mk(U.up[0], U.up[1], U.up[2]), fwd = mk(U.forward[0], U.forward[1], U.forward[2]);
+  V3 d = normalize3(fma3(2.5f, fwd, fma3(uy, up, right * ux)));
+  od6[0] = U.position[0]; od6[1] = U.position[1]; od6[2] = U.position[2]; od6[3] = d.x; od6[4] = d.y; od6[5] = d.z;
+}

@@ -1,0 +1,33 @@
+"""Locating / building the in-tree shared libraries.  No fallbacks: a missing library is an error."""
+import ctypes
+import os
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG_DIR)
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def _load(name, make_target):
+    path = os.path.join(PKG_DIR, name)
+    if not os.path.exists(path):
+        # build in tree (hipcc cross-compiles gfx950 without a GPU); never silently substitute
+        try:
+            subprocess.check_call(["make", "-C", ROOT, make_target], stdout=subprocess.DEVNULL)
+        except Exception as e:  # pragma: no cover
+            raise NativeLibraryError("%s is not built and `make %s` failed: %s" % (name, make_target, e))
+    try:
+        return ctypes.CDLL(path)
+    except OSError as e:
+        raise NativeLibraryError("cannot load %s: %s" % (path, e))
+
+
+def load_rt():
+    return _load("librt_mi355x.so", "vulkan_raytracing_amd/librt_mi355x.so")
+
+
+def load_host():
+    return _load("librt_host.so", "vulkan_raytracing_amd/librt_host.so")

@@ -1,0 +1,245 @@
+// bvh_build.cpp — binned-SAH BVH2 builder producing the 64-byte two-child-box node layout of
+// rt_device.h.  Replaces what the Vulkan driver does behind vkCmdBuildAccelerationStructuresKHR
+// (reference src/main.cpp:495-498 for BLAS, :730-733 for TLAS build/update).  Deterministic: the
+// same input always yields the same tree, so every GPU of a multi-GPU job holds identical BVHs.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace rt {
+namespace {
+
+constexpr float BIG = 3.0e38f;
+constexpr int NBINS = 32;
+
+struct Ref {
+  Aabb box;
+  float c[3];
+  uint32_t id;
+};
+
+inline void box_reset(Aabb& b) {
+  for (int k = 0; k < 3; k++) { b.lo[k] = BIG; b.hi[k] = -BIG; }
+}
+inline void box_grow(Aabb& b, const Aabb& o) {
+  for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], o.lo[k]); b.hi[k] = std::max(b.hi[k], o.hi[k]); }
+}
+inline float half_area(const Aabb& b) {
+  float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  if (dx < 0.f || dy < 0.f || dz < 0.f) return 0.f;
+  return dx * dy + dy * dz + dz * dx;
+}
+// minimum number of levels a subtree of n primitives needs below its root
+inline int levels_needed(uint32_t n, int max_leaf) {
+  uint32_t leaves = (n + (uint32_t)max_leaf - 1) / (uint32_t)max_leaf;
+  int l = 0;
+  while ((1ull << l) < leaves) l++;
+  return l;
+}
+
+struct Builder {
+  std::vector<Ref> refs;
+  int max_leaf, max_depth;
+  BuiltBvh* out;
+
+  int build(uint32_t first, uint32_t count, int depth) {
+    int me = (int)out->topo.size();
+    out->topo.push_back(BuildNode{});
+    out->depth = std::max(out->depth, depth);
+    Aabb bounds, cb;
+    box_reset(bounds); box_reset(cb);
+    for (uint32_t i = first; i < first + count; i++) {
+      box_grow(bounds, refs[i].box);
+      for (int k = 0; k < 3; k++) { cb.lo[k] = std::min(cb.lo[k], refs[i].c[k]); cb.hi[k] = std::max(cb.hi[k], refs[i].c[k]); }
+    }
+    out->topo[me].box = bounds;
+    out->topo[me].first = first;
+    if (count <= 1) { out->topo[me].count = count; out->leaves++; return me; }
+
+    // ---- best SAH split over 3 axes, NBINS bins each
+    float best_cost = BIG; int best_axis = -1, best_bin = -1;
+    for (int axis = 0; axis < 3; axis++) {
+      float ext = cb.hi[axis] - cb.lo[axis];
+      if (!(ext > 0.f)) continue;
+      uint32_t cnt[NBINS] = {0};
+      Aabb bb[NBINS];
+      for (int b = 0; b < NBINS; b++) box_reset(bb[b]);
+      float scale = (float)NBINS / ext;
+      for (uint32_t i = first; i < first + count; i++) {
+        int b = (int)((refs[i].c[axis] - cb.lo[axis]) * scale);
+        b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+        cnt[b]++; box_grow(bb[b], refs[i].box);
+      }
+      float la[NBINS]; uint32_t lc[NBINS];
+      Aabb acc; box_reset(acc); uint32_t c = 0;
+      for (int b = 0; b < NBINS; b++) { c += cnt[b]; box_grow(acc, bb[b]); la[b] = half_area(acc); lc[b] = c; }
+      box_reset(acc); c = 0;
+      for (int b = NBINS - 1; b >= 1; b--) {
+        c += cnt[b]; box_grow(acc, bb[b]);
+        uint32_t nl = lc[b - 1], nr = c;
+        if (nl == 0 || nr == 0) continue;
+        float cost = la[b - 1] * (float)nl + half_area(acc) * (float)nr;
+        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b - 1; }
+      }
+    }
+    float pa = half_area(bounds);
+    if (count <= (uint32_t)max_leaf) {
+      float leaf_cost = pa * (float)count;
+      float split_cost = best_axis >= 0 ? pa * 1.0f + best_cost : BIG;
+      if (leaf_cost <= split_cost) { out->topo[me].count = count; out->leaves++; return me; }
+    }
+    uint32_t mid = first;
+    bool ok = false;
+    int budget = max_depth - depth - 1;  // levels available below each child
+    if (best_axis >= 0) {
+      float ext = cb.hi[best_axis] - cb.lo[best_axis];
+      float scale = (float)NBINS / ext; float lo = cb.lo[best_axis]; int ax = best_axis, bbin = best_bin;
+      auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref& r) {
+        int b = (int)((r.c[ax] - lo) * scale);
+        b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+        return b <= bbin;
+      });
+      mid = (uint32_t)(it - refs.begin());
+      uint32_t nl = mid - first, nr = count - nl;
+      ok = nl > 0 && nr > 0 && levels_needed(nl, max_leaf) <= budget && levels_needed(nr, max_leaf) <= budget;
+    }
+    if (!ok) {  // balanced median split on the widest centroid axis (keeps the depth bound)
+      int ax = 0;
+      for (int k = 1; k < 3; k++) if (cb.hi[k] - cb.lo[k] > cb.hi[ax] - cb.lo[ax]) ax = k;
+      mid = first + count / 2;
+      std::nth_element(refs.begin() + first, refs.begin() + mid, refs.begin() + first + count,
+                       [ax](const Ref& a, const Ref& b) { return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.id < b.id); });
+    }
+    int l = build(first, mid - first, depth + 1);
+    int r = build(mid, first + count - mid, depth + 1);
+    out->topo[me].left = l; out->topo[me].right = r;
+    return me;
+  }
+};
+
+inline void set_child_box(BvhNode& n, int which, const Aabb& b) {
+  if (which == 0) {
+    n.a[0] = b.lo[0]; n.a[1] = b.hi[0]; n.a[2] = b.lo[1]; n.a[3] = b.hi[1]; n.c[0] = b.lo[2]; n.c[1] = b.hi[2];
+  } else {
+    n.b[0] = b.lo[0]; n.b[1] = b.hi[0]; n.b[2] = b.lo[1]; n.b[3] = b.hi[1]; n.c[2] = b.lo[2]; n.c[3] = b.hi[2];
+  }
+}
+inline Aabb missing_box() {
+  Aabb b; for (int k = 0; k < 3; k++) { b.lo[k] = BIG; b.hi[k] = BIG; } return b;
+}
+
+struct Emitter {
+  BuiltBvh* bvh;
+  bool direct_ids;
+  int32_t leaf_ref(const BuildNode& t) const {
+    if (direct_ids) return ~(int32_t)bvh->order[t.first];
+    return ~(int32_t)((t.first << 3) | (t.count - 1));
+  }
+  int32_t emit(int ti) {
+    const BuildNode t = bvh->topo[ti];
+    if (t.left < 0) return leaf_ref(t);
+    int32_t e = (int32_t)bvh->nodes.size();
+    bvh->nodes.push_back(BvhNode{});
+    bvh->emit_of[ti] = e;
+    set_child_box(bvh->nodes[e], 0, bvh->topo[t.left].box);
+    set_child_box(bvh->nodes[e], 1, bvh->topo[t.right].box);
+    int32_t c0 = emit(t.left);
+    int32_t c1 = emit(t.right);
+    bvh->nodes[e].child0 = c0; bvh->nodes[e].child1 = c1;
+    return e;
+  }
+};
+
+}  // namespace
+
+static void build_bvh_impl(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, bool direct_ids, BuiltBvh& out) {
+  out = BuiltBvh{};
+  box_reset(out.bounds);
+  Builder b;
+  b.max_leaf = std::max(1, std::min(8, max_leaf));
+  b.max_depth = std::max(max_depth, levels_needed(std::max(1u, n), b.max_leaf) + 1);
+  b.out = &out;
+  b.refs.resize(n);
+  for (uint32_t i = 0; i < n; i++) {
+    b.refs[i].box = prim_boxes[i]; b.refs[i].id = i;
+    for (int k = 0; k < 3; k++) b.refs[i].c[k] = 0.5f * prim_boxes[i].lo[k] + 0.5f * prim_boxes[i].hi[k];
+    box_grow(out.bounds, prim_boxes[i]);
+  }
+  if (n > 0) b.build(0, n, 0);
+  out.order.resize(n);
+  for (uint32_t i = 0; i < n; i++) out.order[i] = b.refs[i].id;
+  out.emit_of.assign(out.topo.size(), -1);
+  Emitter em{&out, direct_ids};
+  if (n == 0 || out.topo[0].left < 0) {
+    // root must be interior: wrap the single leaf (or nothing) in a synthetic node
+    BvhNode root{};
+    set_child_box(root, 0, n ? out.topo[0].box : missing_box());
+    set_child_box(root, 1, missing_box());
+    root.child0 = n ? em.leaf_ref(out.topo[0]) : ~0;
+    root.child1 = ~0;
+    out.nodes.push_back(root);
+  } else {
+    em.emit(0);
+  }
+}
+
+void build_bvh(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, BuiltBvh& out) {
+  build_bvh_impl(prim_boxes, n, max_leaf, max_depth, max_leaf == 1, out);
+}
+
+static void refit_rec(const Aabb* prim_boxes, BuiltBvh& bvh, int ti) {
+  BuildNode& t = bvh.topo[ti];
+  if (t.left < 0) {
+    box_reset(t.box);
+    for (uint32_t i = t.first; i < t.first + t.count; i++) box_grow(t.box, prim_boxes[bvh.order[i]]);
+    return;
+  }
+  refit_rec(prim_boxes, bvh, t.left);
+  refit_rec(prim_boxes, bvh, t.right);
+  box_reset(t.box);
+  box_grow(t.box, bvh.topo[t.left].box);
+  box_grow(t.box, bvh.topo[t.right].box);
+  int e = bvh.emit_of[ti];
+  if (e >= 0) {
+    set_child_box(bvh.nodes[e], 0, bvh.topo[t.left].box);
+    set_child_box(bvh.nodes[e], 1, bvh.topo[t.right].box);
+  }
+}
+
+void refit_bvh(const Aabb* prim_boxes, BuiltBvh& bvh) {
+  if (bvh.topo.empty()) return;
+  refit_rec(prim_boxes, bvh, 0);
+  bvh.bounds = bvh.topo[0].box;
+  if (bvh.topo[0].left < 0) set_child_box(bvh.nodes[0], 0, bvh.topo[0].box);
+}
+
+void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris) {
+  std::vector<Aabb> boxes(n_prims);
+  for (uint32_t p = 0; p < n_prims; p++) {
+    Aabb b; box_reset(b);
+    for (int c = 0; c < 3; c++) {
+      const float* v = verts6 + 6ull * idx[3ull * p + c];
+      for (int k = 0; k < 3; k++) { b.lo[k] = std::min(b.lo[k], v[k]); b.hi[k] = std::max(b.hi[k], v[k]); }
+    }
+    boxes[p] = b;
+  }
+  build_bvh_impl(boxes.data(), n_prims, 4, BLAS_MAX_DEPTH, false, bvh);
+  tris.resize(n_prims);
+  for (uint32_t i = 0; i < n_prims; i++) {
+    uint32_t p = bvh.order[i];
+    const float* v0 = verts6 + 6ull * idx[3ull * p + 0];
+    const float* v1 = verts6 + 6ull * idx[3ull * p + 1];
+    const float* v2 = verts6 + 6ull * idx[3ull * p + 2];
+    TriPacket& t = tris[i];
+    for (int k = 0; k < 3; k++) {
+      t.v0[k] = v0[k];
+      t.e1[k] = v1[k] - v0[k];   // one binary32 rounding, identical to the oracle's v1 - v0
+      t.e2[k] = v2[k] - v0[k];
+    }
+    t.prim = p; t.pad[0] = t.pad[1] = 0;
+  }
+}
+
+}  // namespace rt

@@ -1,0 +1,44 @@
+// bvh_build.h — host-side acceleration-structure builder (replaces the driver work behind
+// vkCmdBuildAccelerationStructuresKHR, reference src/main.cpp:495-498 (BLAS) and :730-733 (TLAS)).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct Aabb {
+  float lo[3], hi[3];
+};
+
+// Topology kept on the host so a TLAS can be refitted in place (Vulkan UPDATE mode).
+struct BuildNode {
+  Aabb box;
+  int32_t left = -1, right = -1;  // BuildNode indices, -1 for leaves
+  uint32_t first = 0, count = 0;  // leaf: range in the reordered primitive list
+};
+
+struct BuiltBvh {
+  std::vector<BvhNode> nodes;     // node 0 is the root and is always interior
+  std::vector<uint32_t> order;    // leaf order -> original primitive index
+  std::vector<BuildNode> topo;    // build tree (topo[0] = root)
+  std::vector<int32_t> emit_of;   // topo index -> index in nodes (interior) or -1
+  Aabb bounds;
+  int depth = 0;
+  uint32_t leaves = 0;
+};
+
+// Binned-SAH BVH2 over primitive boxes.  max_leaf in 1..8; max_depth bounds the tree depth
+// (median splits take over where SAH would exceed it), which bounds the traversal stack.
+void build_bvh(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, BuiltBvh& out);
+
+// Recompute every box of `bvh` bottom-up from new primitive boxes, keeping the topology, and
+// rewrite bvh.nodes in place.
+void refit_bvh(const Aabb* prim_boxes, BuiltBvh& bvh);
+
+// BLAS helper: boxes + 48-byte packets for an indexed triangle mesh in the reference's layout
+// (positions at verts6[6*i .. 6*i+2], object-local uint32 indices).
+void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris);
+
+}  // namespace rt

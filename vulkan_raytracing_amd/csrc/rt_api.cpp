@@ -1,0 +1,582 @@
+// rt_api.cpp — the C ABI of include/rt_api.h: context, HBM residency, acceleration-structure
+// management and the per-frame kernel pipeline.  Host counterpart of the Vulkan plumbing the
+// reference inlines in main() (src/main.cpp:305-793 BLAS/TLAS, :1660-1729 buffers, :1847-1889 UBO,
+// :2061-2412 cube map, :2620-2624 vkCmdTraceRaysKHR).  There is NO CPU fallback: without a HIP
+// device every entry point fails with RT_ERR_NO_DEVICE / RT_ERR_DEVICE.
+#include "../../include/rt_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "rt_device.h"
+#include "rt_kernels.h"
+
+using namespace rt;
+
+static_assert(sizeof(rt_instance) == 64, "rt_instance must mirror VkAccelerationStructureInstanceKHR (64 B)");
+static_assert(sizeof(rt_uniforms) == 104, "rt_uniforms must mirror UniformStructure (104 B)");
+static_assert(sizeof(rt_uniforms) == sizeof(UniformsDev), "uniform mirrors out of sync");
+static_assert(sizeof(rt_hit) == sizeof(HitRec), "hit mirrors out of sync");
+static_assert(sizeof(rt_mesh_range) == 24, "rt_mesh_range layout");
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Mesh {
+  rt_mesh_range range{};
+  bool built = false;
+  BuiltBvh bvh;
+  std::vector<TriPacket> tris;
+  int32_t node_base = 0;   // position of this mesh's nodes / packets in the linked arrays
+  uint32_t tri_base = 0;
+};
+
+struct TimedSpan { int cat; hipEvent_t a, b; };
+enum { CAT_RAYGEN = 0, CAT_TRACE, CAT_SHADE, CAT_SHADOW, CAT_RESOLVE, CAT_FRAME, CAT_N };
+
+}  // namespace
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  std::string info;
+  int n_cu = 0;
+
+  // geometry (bindings 2/3)
+  std::vector<float> h_verts;
+  std::vector<uint32_t> h_idx;
+  float* d_verts = nullptr;
+  uint32_t* d_idx = nullptr;
+  std::vector<Mesh> meshes;
+  bool blas_linked = false;
+  BvhNode* d_blas_nodes = nullptr;
+  float4* d_tris = nullptr;
+  size_t n_blas_nodes = 0, n_tris = 0;
+
+  // instances / TLAS (binding 0)
+  std::vector<rt_instance> h_inst;
+  std::vector<InstanceDev> h_inst_dev;
+  BuiltBvh tlas;
+  bool tlas_valid = false;
+  InstanceDev* d_inst = nullptr;
+  BvhNode* d_tlas_nodes = nullptr;
+  size_t cap_inst = 0, cap_tlas_nodes = 0;
+
+  // uniforms (binding 1), cube map (binding 5)
+  UniformsDev uni{};
+  bool have_uni = false;
+  uchar4* d_sky = nullptr;
+  int sky_w = 0, sky_h = 0;
+
+  // frame state
+  FrameDev frame{};
+  size_t frame_capacity = 0;     // rays
+  size_t out_capacity = 0;       // float4 pixels in lib-owned output
+  float4* d_out_own = nullptr;
+  uint32_t* d_counters = nullptr;
+  int32_t* d_ovf = nullptr;
+  LaunchCfg cfg{};
+  bool timing = false;
+  bool counting = false;
+  std::vector<hipEvent_t> ev_pool;
+  size_t ev_used = 0;
+  std::vector<TimedSpan> spans;
+  rt_stats last{};
+  bool frame_pending = false;
+  hipStream_t frame_stream = nullptr;
+  uint32_t last_max_bounce = 0;
+  uint64_t last_primary = 0;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) {
+  if (c) c->error = msg; else g_create_error = msg;
+  return code;
+}
+#define HIP_TRY(c, expr)                                                                          \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess)                                                                         \
+      return fail(c, e_ == hipErrorOutOfMemory ? RT_ERR_OUT_OF_MEMORY : RT_ERR_DEVICE,            \
+                  std::string("HIP runtime exception: return code ") + std::to_string((int)e_) +  \
+                      " (" + hipGetErrorString(e_) + ") in " #expr);                              \
+  } while (0)
+
+// inverse of a row-major 3x4 affine map in binary64, rounded once (gl_WorldToObjectEXT)
+void invert_affine(const float m[12], float out[12]) {
+  double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+  double tx = m[3], ty = m[7], tz = m[11];
+  double c00 = e * i - f * h, c01 = c * h - b * i, c02 = b * f - c * e;
+  double c10 = f * g - d * i, c11 = a * i - c * g, c12 = c * d - a * f;
+  double c20 = d * h - e * g, c21 = b * g - a * h, c22 = a * e - b * d;
+  double det = a * c00 + b * c10 + c * c20;
+  double r = 1.0 / det;
+  double n[9] = {c00 * r, c01 * r, c02 * r, c10 * r, c11 * r, c12 * r, c20 * r, c21 * r, c22 * r};
+  out[0] = (float)n[0]; out[1] = (float)n[1]; out[2] = (float)n[2];
+  out[4] = (float)n[3]; out[5] = (float)n[4]; out[6] = (float)n[5];
+  out[8] = (float)n[6]; out[9] = (float)n[7]; out[10] = (float)n[8];
+  out[3] = (float)(-(n[0] * tx + n[1] * ty + n[2] * tz));
+  out[7] = (float)(-(n[3] * tx + n[4] * ty + n[5] * tz));
+  out[11] = (float)(-(n[6] * tx + n[7] * ty + n[8] * tz));
+}
+
+// world-space box of an instance: 8 transformed corners of the BLAS bounds, padded so that the
+// binary32 roundings of the transform can never make it non-conservative.
+Aabb instance_world_box(const float o2w[12], const Aabb& b) {
+  Aabb w; for (int k = 0; k < 3; k++) { w.lo[k] = 3.0e38f; w.hi[k] = -3.0e38f; }
+  if (b.lo[0] > b.hi[0]) { for (int k = 0; k < 3; k++) w.lo[k] = w.hi[k] = 3.0e38f; return w; }  // empty mesh
+  float mag = 0.f;
+  for (int cx = 0; cx < 8; cx++) {
+    double p[3] = {(cx & 1) ? b.hi[0] : b.lo[0], (cx & 2) ? b.hi[1] : b.lo[1], (cx & 4) ? b.hi[2] : b.lo[2]};
+    for (int r = 0; r < 3; r++) {
+      double v = o2w[4 * r] * p[0] + o2w[4 * r + 1] * p[1] + o2w[4 * r + 2] * p[2] + o2w[4 * r + 3];
+      w.lo[r] = std::min(w.lo[r], (float)v); w.hi[r] = std::max(w.hi[r], (float)v);
+      mag = std::max(mag, (float)std::fabs(v));
+    }
+  }
+  float pad = 1e-5f * mag + 1e-30f;
+  for (int k = 0; k < 3; k++) { w.lo[k] -= pad; w.hi[k] += pad; }
+  return w;
+}
+
+int link_blas(rt_ctx* c) {
+  // concatenate every built mesh into one node array / one packet array with global references
+  size_t nn = 0, nt = 0;
+  for (auto& m : c->meshes) {
+    if (!m.built) continue;
+    m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt;
+    nn += m.bvh.nodes.size(); nt += m.tris.size();
+  }
+  std::vector<BvhNode> nodes(nn);
+  std::vector<TriPacket> tris(nt);
+  for (auto& m : c->meshes) {
+    if (!m.built) continue;
+    for (size_t i = 0; i < m.bvh.nodes.size(); i++) {
+      BvhNode n = m.bvh.nodes[i];
+      auto fix = [&](int32_t ch) -> int32_t {
+        if (ch >= 0) return ch + m.node_base;
+        uint32_t ref = (uint32_t)(~ch);
+        uint32_t first = (ref >> 3) + m.tri_base, cnt = ref & 7u;
+        return ~(int32_t)((first << 3) | cnt);
+      };
+      n.child0 = fix(n.child0); n.child1 = fix(n.child1);
+      nodes[m.node_base + i] = n;
+    }
+    if (!m.tris.empty()) memcpy(&tris[m.tri_base], m.tris.data(), m.tris.size() * sizeof(TriPacket));
+  }
+  if (c->d_blas_nodes) { HIP_TRY(c, hipFree(c->d_blas_nodes)); c->d_blas_nodes = nullptr; }
+  if (c->d_tris) { HIP_TRY(c, hipFree(c->d_tris)); c->d_tris = nullptr; }
+  HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, std::max<size_t>(1, nn) * sizeof(BvhNode)));
+  HIP_TRY(c, hipMalloc((void**)&c->d_tris, std::max<size_t>(1, nt) * sizeof(TriPacket)));
+  if (nn) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, nodes.data(), nn * sizeof(BvhNode), hipMemcpyHostToDevice));
+  if (nt) HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriPacket), hipMemcpyHostToDevice));
+  c->n_blas_nodes = nn; c->n_tris = nt;
+  c->blas_linked = true;
+  return RT_OK;
+}
+
+int upload_instances(rt_ctx* c) {
+  const size_t n = c->h_inst_dev.size();
+  if (n > c->cap_inst) {
+    if (c->d_inst) HIP_TRY(c, hipFree(c->d_inst));
+    HIP_TRY(c, hipMalloc((void**)&c->d_inst, n * sizeof(InstanceDev)));
+    c->cap_inst = n;
+  }
+  if (c->tlas.nodes.size() > c->cap_tlas_nodes) {
+    if (c->d_tlas_nodes) HIP_TRY(c, hipFree(c->d_tlas_nodes));
+    HIP_TRY(c, hipMalloc((void**)&c->d_tlas_nodes, c->tlas.nodes.size() * sizeof(BvhNode)));
+    c->cap_tlas_nodes = c->tlas.nodes.size();
+  }
+  // stream-ordered so a per-frame update never stalls the host on a fence (the reference blocks on
+  // vkWaitForFences every frame, src/main.cpp:772-778)
+  HIP_TRY(c, hipMemcpyAsync(c->d_inst, c->h_inst_dev.data(), n * sizeof(InstanceDev), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_tlas_nodes, c->tlas.nodes.data(), c->tlas.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rewritten by the next call
+  return RT_OK;
+}
+
+SceneDev scene_dev(const rt_ctx* c) {
+  SceneDev s{};
+  s.blas_nodes = c->d_blas_nodes; s.tris = c->d_tris; s.tlas_nodes = c->d_tlas_nodes; s.inst = c->d_inst;
+  s.verts = c->d_verts; s.idx = c->d_idx; s.sky = c->d_sky; s.n_inst = (int)c->h_inst_dev.size();
+  s.sky_w = c->sky_w; s.sky_h = c->sky_h;
+  return s;
+}
+
+int ready_to_trace(rt_ctx* c) {
+  if (!c->d_verts) return fail(c, RT_ERR_NOT_READY, "rt_upload_geometry has not been called");
+  if (!c->tlas_valid) return fail(c, RT_ERR_NOT_READY, "rt_set_instances has not been called");
+  if (!c->blas_linked) { int r = link_blas(c); if (r) return r; }
+  return RT_OK;
+}
+
+int ensure_common(rt_ctx* c) {
+  if (!c->d_counters) HIP_TRY(c, hipMalloc((void**)&c->d_counters, CNT_WORDS * sizeof(uint32_t)));
+  if (!c->d_ovf) HIP_TRY(c, hipMalloc((void**)&c->d_ovf, (size_t)c->cfg.trace_blocks * 256 * STACK_OVF * sizeof(int32_t)));
+  return RT_OK;
+}
+
+int ensure_frame(rt_ctx* c, size_t capacity) {
+  int r = ensure_common(c); if (r) return r;
+  if (capacity <= c->frame_capacity) return RT_OK;
+  FrameDev& f = c->frame;
+  void** ptrs[] = {(void**)&f.ray_o[0], (void**)&f.ray_o[1], (void**)&f.ray_d[0], (void**)&f.ray_d[1], (void**)&f.hit_a,
+                   (void**)&f.sh_o, (void**)&f.sh_d, (void**)&f.sh_c, (void**)&f.sample_color};
+  for (void** p : ptrs) { if (*p) HIP_TRY(c, hipFree(*p)); *p = nullptr; }
+  if (f.hit_inst) { HIP_TRY(c, hipFree(f.hit_inst)); f.hit_inst = nullptr; }
+  c->frame_capacity = 0;
+  for (void** p : ptrs) HIP_TRY(c, hipMalloc(p, capacity * sizeof(float4)));
+  HIP_TRY(c, hipMalloc((void**)&f.hit_inst, capacity * sizeof(int32_t)));
+  c->frame_capacity = capacity;
+  return RT_OK;
+}
+
+hipEvent_t take_event(rt_ctx* c) {
+  if (c->ev_used == c->ev_pool.size()) { hipEvent_t e; hipEventCreate(&e); c->ev_pool.push_back(e); }
+  return c->ev_pool[c->ev_used++];
+}
+
+struct Span {
+  rt_ctx* c; int cat; hipStream_t s; hipEvent_t a = nullptr;
+  Span(rt_ctx* c_, int cat_, hipStream_t s_) : c(c_), cat(cat_), s(s_) {
+    if (c->timing) { a = take_event(c); hipEventRecord(a, s); }
+  }
+  ~Span() {
+    if (c->timing) { hipEvent_t b = take_event(c); hipEventRecord(b, s); c->spans.push_back({cat, a, b}); }
+  }
+};
+
+int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, float4* d_out, hipStream_t s) {
+  const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
+  const UniformsDev& u = c->uni;
+  if (u.samples_per_pixel == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "samplesPerPixel must be >= 1");
+  if (u.max_bounce_count + 2 > (uint32_t)CNT_MAX_BOUNCES) return fail(c, RT_ERR_INVALID_ARGUMENT, "maxBounceCount too large (max 69)");
+  const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
+  const size_t capacity = tiles * u.samples_per_pixel * 64;
+  if (capacity >= 0xFFFFFF00ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for 32-bit sample ids");
+  int r = ensure_frame(c, std::max<size_t>(capacity, 64)); if (r) return r;
+  FrameDev f = c->frame;
+  f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out;
+  f.capacity = (uint32_t)capacity; f.width = W; f.height = H; f.rows = rows;
+  f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
+  const SceneDev sc = scene_dev(c);
+  c->ev_used = 0; c->spans.clear();
+  c->frame_stream = s; c->frame_pending = true;
+  c->last_max_bounce = u.max_bounce_count;
+  c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
+  if (rows == 0) { HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s)); return RT_OK; }
+  {
+    Span frame_span(c, CAT_FRAME, s);
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s));
+    { Span sp(c, CAT_RAYGEN, s); launch_raygen(f, u, s); }
+    for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
+      { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
+      { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); }
+      if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
+        // deep bounce budgets (the reference default is 63): stop launching once every path has ended
+        uint32_t live = 0;
+        HIP_TRY(c, hipMemcpyAsync(&live, c->d_counters + CNT_QUEUE0 + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipStreamSynchronize(s));
+        if (live == 0) break;
+      }
+    }
+    { Span sp(c, CAT_SHADOW, s); launch_trace_shadow(sc, f, c->counting, c->cfg, s); }
+    { Span sp(c, CAT_RESOLVE, s); launch_resolve(f, u, s); }
+  }
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
+int collect_stats(rt_ctx* c) {
+  if (!c->frame_pending) return RT_OK;
+  HIP_TRY(c, hipStreamSynchronize(c->frame_stream));
+  uint32_t cnt[CNT_WORDS];
+  HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  rt_stats st{};
+  st.rays_primary = c->last_primary;
+  for (uint32_t b = 1; b <= c->last_max_bounce; b++) st.rays_secondary += cnt[CNT_QUEUE0 + b];
+  st.rays_shadow = cnt[CNT_SHADOW];
+  st.closest_rays = st.rays_primary + st.rays_secondary;
+  memcpy(&st.node_visits, &cnt[CNT_NODE_VISITS], 8);
+  memcpy(&st.tri_tests, &cnt[CNT_TRI_TESTS], 8);
+  st.bvh_node_bytes = sizeof(BvhNode); st.bvh_tri_bytes = sizeof(TriPacket);
+  for (auto& sp : c->spans) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
+    switch (sp.cat) {
+      case CAT_RAYGEN: st.ms_raygen += ms; break;
+      case CAT_TRACE: st.ms_trace_closest += ms; st.launches_trace_closest++; break;
+      case CAT_SHADE: st.ms_shade += ms; break;
+      case CAT_SHADOW: st.ms_trace_shadow += ms; break;
+      case CAT_RESOLVE: st.ms_resolve += ms; break;
+      case CAT_FRAME: st.ms_frame += ms; break;
+    }
+    if (sp.cat != CAT_FRAME) st.launches_total++;
+  }
+  c->last = st;
+  c->frame_pending = false;
+  return RT_OK;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int rt_abi_version(void) { return 1; }
+
+int rt_create(rt_ctx** out_ctx, int device_id) {
+  if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+  *out_ctx = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0)
+    return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device available (librt_mi355x has no CPU fallback)");
+  if (device_id < 0 || device_id >= n) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "device_id out of range");
+  HIP_TRY(nullptr, hipSetDevice(device_id));
+  hipDeviceProp_t prop;
+  HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    return fail(nullptr, RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library contains gfx950 code only");
+  rt_ctx* c = new rt_ctx();
+  c->device = device_id;
+  c->n_cu = prop.multiProcessorCount;
+  c->info = std::string("gfx950 ") + prop.name + " CUs=" + std::to_string(prop.multiProcessorCount);
+  if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_DEVICE, "hipStreamCreate failed"); }
+  // persistent grids: LDS stacks (24 KB per 256-thread block) admit 6 blocks per CU
+  c->cfg.trace_blocks = c->n_cu * 6;
+  c->cfg.shade_blocks = c->n_cu * 8;
+  if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
+  *out_ctx = c;
+  return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  FrameDev& f = c->frame;
+  void* ptrs[] = {c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_tlas_nodes, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
+                  f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
+  for (void* p : ptrs) if (p) hipFree(p);
+  for (auto e : c->ev_pool) hipEventDestroy(e);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+}
+
+const char* rt_last_error(const rt_ctx* c) { return c ? c->error.c_str() : g_create_error.c_str(); }
+const char* rt_device_info(const rt_ctx* c) { return c ? c->info.c_str() : ""; }
+
+int rt_upload_geometry(rt_ctx* c, const float* verts6, size_t n_floats, const uint32_t* idx, size_t n_idx,
+                       const rt_mesh_range* ranges, int n_meshes) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (!verts6 || !idx || !ranges || n_meshes <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "null geometry pointers or no meshes");
+  if (n_floats % 6 != 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "vertex buffer must hold 6 floats per vertex");
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (int m = 0; m < n_meshes; m++) {
+    const rt_mesh_range& r = ranges[m];
+    if (r.first_index + 3ull * r.prim_count > n_idx || r.first_float % 6 != 0 || r.first_float > n_floats)
+      return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh range " + std::to_string(m) + " exceeds the buffers");
+    const uint64_t nv = (n_floats - r.first_float) / 6;
+    for (uint64_t k = 0; k < 3ull * r.prim_count; k++)
+      if (idx[r.first_index + k] >= nv) return fail(c, RT_ERR_INVALID_ARGUMENT, "index out of range in mesh " + std::to_string(m));
+  }
+  c->h_verts.assign(verts6, verts6 + n_floats);
+  c->h_idx.assign(idx, idx + n_idx);
+  if (c->d_verts) HIP_TRY(c, hipFree(c->d_verts));
+  if (c->d_idx) HIP_TRY(c, hipFree(c->d_idx));
+  c->d_verts = nullptr; c->d_idx = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&c->d_verts, std::max<size_t>(n_floats, 6) * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void**)&c->d_idx, std::max<size_t>(n_idx, 3) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemcpy(c->d_verts, verts6, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(c->d_idx, idx, n_idx * sizeof(uint32_t), hipMemcpyHostToDevice));
+  c->meshes.assign(n_meshes, Mesh{});
+  for (int m = 0; m < n_meshes; m++) c->meshes[m].range = ranges[m];
+  c->blas_linked = false; c->tlas_valid = false;
+  return RT_OK;
+}
+
+int rt_build_blas(rt_ctx* c, int mesh) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
+  Mesh& m = c->meshes[mesh];
+  build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
+  m.built = true;
+  c->blas_linked = false; c->tlas_valid = false;
+  return RT_OK;
+}
+
+int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (!inst || n <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "no instances");
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (int i = 0; i < n; i++) {
+    if (inst[i].mesh >= c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance references an unknown mesh");
+    if (!c->meshes[inst[i].mesh].built) return fail(c, RT_ERR_NOT_READY, "instance references a mesh whose BLAS is not built (rt_build_blas)");
+  }
+  if (update && (!c->tlas_valid || (int)c->h_inst.size() != n))
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "TLAS update needs a previous build with the same instance count");
+  if (!c->blas_linked) { int r = link_blas(c); if (r) return r; }
+  c->h_inst.assign(inst, inst + n);
+  c->h_inst_dev.resize(n);
+  std::vector<Aabb> boxes(n);
+  for (int i = 0; i < n; i++) {
+    InstanceDev& d = c->h_inst_dev[i];
+    const Mesh& m = c->meshes[inst[i].mesh];
+    memcpy(d.o2w, inst[i].transform, sizeof(d.o2w));
+    invert_affine(d.o2w, d.w2o);
+    d.blas_root = m.node_base;
+    d.mask = inst[i].custom_index_and_mask >> 24;
+    d.custom_index = (int32_t)(inst[i].custom_index_and_mask & 0xFFFFFFu);
+    d.first_float = (uint32_t)m.range.first_float;
+    d.first_index = (uint32_t)m.range.first_index;
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    boxes[i] = instance_world_box(d.o2w, m.bvh.bounds);
+  }
+  if (update) refit_bvh(boxes.data(), c->tlas);
+  else build_bvh(boxes.data(), (uint32_t)n, 1, 20, c->tlas);
+  c->tlas_valid = true;
+  return upload_instances(c);
+}
+
+int rt_set_uniforms(rt_ctx* c, const rt_uniforms* u) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (!u) return fail(c, RT_ERR_INVALID_ARGUMENT, "uniforms pointer is NULL");
+  memcpy(&c->uni, u, sizeof(UniformsDev));
+  c->have_uni = true;
+  return RT_OK;
+}
+
+int rt_set_skybox(rt_ctx* c, const uint8_t* const faces[6], int w, int h) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (!faces || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad skybox arguments");
+  for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RT_ERR_INVALID_ARGUMENT, "skybox face is NULL");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t face_bytes = (size_t)w * h * 4;
+  if (c->d_sky) { HIP_TRY(c, hipFree(c->d_sky)); c->d_sky = nullptr; }
+  HIP_TRY(c, hipMalloc((void**)&c->d_sky, 6 * face_bytes));
+  for (int f = 0; f < 6; f++)
+    HIP_TRY(c, hipMemcpy((uint8_t*)c->d_sky + f * face_bytes, faces[f], face_bytes, hipMemcpyHostToDevice));
+  c->sky_w = w; c->sky_h = h;
+  return RT_OK;
+}
+
+int rt_shard_rows(int height, int band_rows, int shard, int n_shards) {
+  if (height <= 0 || band_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards) return 0;
+  const int n_bands = (height + band_rows - 1) / band_rows;
+  int rows = 0;
+  for (int b = shard; b < n_bands; b += n_shards) rows += std::min(band_rows, height - b * band_rows);
+  return rows;
+}
+
+int rt_set_timing(rt_ctx* c, int enabled) { if (!c) return RT_ERR_INVALID_ARGUMENT; c->timing = enabled != 0; return RT_OK; }
+
+int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t out_capacity_bytes, void* hip_stream) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (W <= 0 || H <= 0 || band_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !d_out)
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace_shard arguments");
+  if (!c->have_uni) return fail(c, RT_ERR_NOT_READY, "rt_set_uniforms has not been called");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = ready_to_trace(c); if (r) return r;
+  const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
+  if ((size_t)rows * W * 16 > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for this shard");
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  return enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
+}
+
+int rt_synchronize(rt_ctx* c) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  HIP_TRY(c, hipSetDevice(c->device));
+  if (c->frame_pending) return collect_stats(c);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  return RT_OK;
+}
+
+int rt_get_stats(rt_ctx* c, rt_stats* st) {
+  if (!c || !st) return RT_ERR_INVALID_ARGUMENT;
+  int r = collect_stats(c); if (r) return r;
+  *st = c->last;
+  return RT_OK;
+}
+
+static int trace_host(rt_ctx* c, int W, int H, float* out, rt_stats* stats, bool counting) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (W <= 0 || H <= 0 || !out) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace arguments");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t px = (size_t)W * H;
+  if (px > c->out_capacity) {
+    if (c->d_out_own) HIP_TRY(c, hipFree(c->d_out_own));
+    c->d_out_own = nullptr; c->out_capacity = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_out_own, px * sizeof(float4)));
+    c->out_capacity = px;
+  }
+  c->counting = counting;
+  int r = rt_trace_shard(c, W, H, H, 0, 1, c->d_out_own, px * sizeof(float4), nullptr);
+  c->counting = false;
+  if (r) return r;
+  r = collect_stats(c); if (r) return r;
+  HIP_TRY(c, hipMemcpy(out, c->d_out_own, px * sizeof(float4), hipMemcpyDeviceToHost));
+  if (stats) *stats = c->last;
+  return RT_OK;
+}
+
+int rt_trace(rt_ctx* c, int W, int H, float* out, rt_stats* stats) { return trace_host(c, W, H, out, stats, false); }
+int rt_trace_counting(rt_ctx* c, int W, int H, float* out, rt_stats* stats) { return trace_host(c, W, H, out, stats, true); }
+
+int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* out, int counting, rt_stats* stats) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if ((!rays8 || !out) && n) return fail(c, RT_ERR_INVALID_ARGUMENT, "null ray/hit pointers");
+  if (n >= 0xFFFFFF00ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "too many rays for one call");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = ready_to_trace(c); if (r) return r;
+  r = ensure_common(c); if (r) return r;
+  if (stats) memset(stats, 0, sizeof(*stats));
+  if (n == 0) return RT_OK;
+  std::vector<float4> ho(n), hd(n);
+  for (size_t i = 0; i < n; i++) {
+    const float* p = rays8 + 8 * i;
+    ho[i] = make_float4(p[0], p[1], p[2], p[3]);
+    hd[i] = make_float4(p[4], p[5], p[6], p[7]);
+  }
+  float4 *d_o = nullptr, *d_d = nullptr; HitRec* d_h = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&d_o, n * sizeof(float4)));
+  HIP_TRY(c, hipMalloc((void**)&d_d, n * sizeof(float4)));
+  HIP_TRY(c, hipMalloc((void**)&d_h, n * sizeof(HitRec)));
+  HIP_TRY(c, hipMemcpy(d_o, ho.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(d_d, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), c->stream));
+  uint32_t n32 = (uint32_t)n;
+  HIP_TRY(c, hipMemcpyAsync(c->d_counters + CNT_QUEUE0, &n32, sizeof(n32), hipMemcpyHostToDevice, c->stream));
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0, c->stream);
+  launch_trace_raw(scene_dev(c), d_o, d_d, d_h, c->d_counters + CNT_QUEUE0, c->d_ovf, c->d_counters, any_hit != 0, counting != 0, c->cfg, c->stream);
+  hipEventRecord(e1, c->stream);
+  HIP_TRY(c, hipStreamSynchronize(c->stream));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpy(out, d_h, n * sizeof(HitRec), hipMemcpyDeviceToHost));
+  if (stats) {
+    uint32_t cnt[CNT_WORDS];
+    HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    memcpy(&stats->node_visits, &cnt[CNT_NODE_VISITS], 8);
+    memcpy(&stats->tri_tests, &cnt[CNT_TRI_TESTS], 8);
+    float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
+    if (any_hit) stats->ms_trace_shadow = ms; else stats->ms_trace_closest = ms;
+    stats->closest_rays = any_hit ? 0 : n; stats->rays_shadow = any_hit ? n : 0;
+    stats->bvh_node_bytes = sizeof(BvhNode); stats->bvh_tri_bytes = sizeof(TriPacket);
+  }
+  hipEventDestroy(e0); hipEventDestroy(e1);
+  hipFree(d_o); hipFree(d_d); hipFree(d_h);
+  return RT_OK;
+}
+
+}  // extern "C"

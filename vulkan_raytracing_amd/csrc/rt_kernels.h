@@ -1,0 +1,56 @@
+// rt_kernels.h — launch interface between the host library (rt_api.cpp) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct SceneDev {
+  const BvhNode* blas_nodes;
+  const float4* tris;          // 3 float4 per TriPacket
+  const BvhNode* tlas_nodes;
+  const InstanceDev* inst;
+  const float* verts;          // binding 3 (src/main.cpp:1305-1335)
+  const uint32_t* idx;         // binding 2
+  const uchar4* sky;           // binding 5: 6 layers RGBA8
+  int n_inst;
+  int sky_w, sky_h;
+};
+
+struct FrameDev {
+  float4* ray_o[2];            // ping-pong ray queues: (o.xyz, tmax)
+  float4* ray_d[2];            //                        (d.xyz, sample id bits)
+  float4* hit_a;               // closest-hit records: (t, u, v, prim bits)
+  int32_t* hit_inst;           //                       instance index, -1 = miss
+  float4* sh_o;                // shadow queue: (o.xyz, tmax = lightDistance)
+  float4* sh_d;                //               (L.xyz, sample id bits)
+  float4* sh_c;                //               (diffuse+specular rgb, 0.9^i)
+  float4* sample_color;        // per-sample tmpColor (rgb, 1), index = i*(rows*W) + ly*W + x
+  uint32_t* counters;          // rt::CNT_* layout
+  int32_t* ovf_stack;          // STACK_OVF ints per persistent thread
+  float4* out;                 // compact shard image (rows x W RGBA32F)
+  uint32_t capacity;           // queue capacity in rays
+  int width, height;           // full frame
+  int rows;                    // rows rendered by this shard (compact)
+  int band_rows, shard, n_shards;
+};
+
+struct LaunchCfg {
+  int trace_blocks;            // persistent grid of the traversal kernels (256 threads each)
+  int shade_blocks;
+};
+
+void launch_raygen(const FrameDev& f, const UniformsDev& u, hipStream_t s);
+void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
+void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
+void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
+void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
+// record-level traceRayEXT on raw rays: o = (o.xyz, tmin), d = (d.xyz, tmax); writes HitRec[n]
+void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, const uint32_t* n_ptr,
+                      int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s);
+
+int trace_threads_per_block();
+
+}  // namespace rt
