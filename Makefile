@@ -24,6 +24,6 @@ clean:
 
 # host-side library (OBJ/MTL ingest, camera, animation, stand-in mesh, JPEG decode) — g++ only
 HOSTSRC := $(CSRC)/host_shim.cpp host/camera.cpp host/standin.cpp $(wildcard host/jpeg_decode.cpp)
-$(PKG)/librt_host.so: $(HOSTSRC) include/rt_host.hpp include/obj_loader.h include/camera.h include/rt_vec.h include/config.h include/rt_api.h
+$(PKG)/librt_host.so: $(HOSTSRC) include/jpeg_decode.h include/rt_host.hpp include/obj_loader.h include/camera.h include/rt_vec.h include/config.h include/rt_api.h
 	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -o $@ $(HOSTSRC)
 all: $(PKG)/librt_host.so

@@ -84,8 +84,10 @@ typedef struct rt_stats {
   uint64_t rays_primary;     /* one count per traceRayEXT-equivalent, by class */
   uint64_t rays_secondary;
   uint64_t rays_shadow;
-  uint64_t node_visits;      /* filled only by rt_trace_counting (instrumented kernels) */
+  uint64_t node_visits;      /* closest-hit kernel; filled only by the instrumented (counting) kernels */
   uint64_t tri_tests;
+  uint64_t node_visits_shadow; /* any-hit kernel, same */
+  uint64_t tri_tests_shadow;
   uint64_t closest_rays;     /* rays through the closest-hit traversal kernel (primary+secondary) */
   float ms_frame;            /* HIP-event time of the whole frame pipeline on the trace stream */
   float ms_raygen;

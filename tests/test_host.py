@@ -1,0 +1,230 @@
+"""CPU tests of the host side above the C ABI and of the ABI surface itself (no GPU, no compute)."""
+import ctypes
+import hashlib
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import ingest
+from tests import scenes
+from vulkan_raytracing_amd import api, host, tiling
+
+ROOT = scenes.ROOT
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """librt_mi355x.so loads here (hipcc cross-compiled) and exports exactly what include/rt_api.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "rt_api.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(rt_[a-z_0-9]+)\s*\(", hdr, re.M))
+    assert declared == set(api.EXPORTS), declared ^ set(api.EXPORTS)
+    L = api.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+    assert L.rt_abi_version() == 1
+    assert L.rt_shard_rows(1080, 8, 0, 8) == tiling.shard_rows(1080, 8, 0, 8)
+
+
+def test_no_gpu_means_loud_failure():
+    """Without a HIP device the product refuses to run (no CPU fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(api.RtError) as e:
+        api.RtContext(0)
+    assert e.value.code in (3, 5)
+
+
+def test_product_never_imports_oracle():
+    """The product path may mention the oracle in comments, but never imports, includes, links or loads it."""
+    pat = re.compile(r"(^\s*(import|from)\s+oracle\b)|(#include\s*[<\"][^>\"]*oracle)|librt_oracle\.so|\borc_[a-z_]+\s*\(", re.M)
+    files = []
+    for dirpath, _, fs in os.walk(os.path.join(ROOT, "vulkan_raytracing_amd")):
+        files += [os.path.join(dirpath, f) for f in fs if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp"))]
+    for d in ("include", "host"):
+        files += [os.path.join(ROOT, d, f) for f in os.listdir(os.path.join(ROOT, d))]
+    files.append(os.path.join(ROOT, "Makefile"))
+    for f in files:
+        txt = open(f).read()
+        if f.endswith("Makefile"):
+            assert "librt_oracle" not in txt.split("oracle:")[0]
+            continue
+        assert not pat.search(txt), f
+
+
+def test_obj_loader_matches_reference_loader_golden(resources):
+    """include/obj_loader.h (through rthost::loadScene) == the reference's vendored tiny_obj_loader.h."""
+    g = json.load(open(os.path.join(GOLD, "ingest_golden.json")))["obj"]
+    for name in ("cube", "teapot", "cube_scene"):
+        s = host.SceneGeometry([os.path.join(resources, name + ".obj")])
+        assert hashlib.sha256(s.idx.tobytes()).hexdigest() == g[name]["vidx.u32"]["sha256"]
+        v = s.verts.reshape(-1, 6)
+        assert hashlib.sha256(np.ascontiguousarray(v[:, 0:3]).tobytes()).hexdigest() == g[name]["vertices.f32"]["sha256"]
+        if g[name]["normals.f32"]["count"] == g[name]["vertices.f32"]["count"]:  # reference behaviour defined
+            assert hashlib.sha256(np.ascontiguousarray(v[:, 3:6]).tobytes()).hexdigest() == g[name]["normals.f32"]["sha256"]
+        assert s.ranges[0][2] == g[name]["vidx.u32"]["count"] // 3
+        o = ingest.SceneArrays([os.path.join(resources, name + ".obj")])
+        assert np.array_equal(o.verts, s.verts) and np.array_equal(o.idx, s.idx)
+
+
+def test_two_object_offsets(resources):
+    s = host.SceneGeometry([os.path.join(resources, "teapot.obj"), os.path.join(resources, "cube.obj")])
+    assert s.ranges == [(0, 0, 2256), (7212, 6768, 12)]
+    assert (s.orbiting_primitive_offset, s.orbiting_vertex_offset) == (2256, 7212)  # src/main.cpp:1872-1873
+
+
+def test_obj_loader_polygons_and_indices(tmp_path):
+    p = tmp_path / "q.obj"
+    p.write_text("v 0 0 0\nv 2 0 0\nv 2 1 0\nv 0 1 0\nv 1 2 0\nvn 0 0 1\n"
+                 "f 1//1 2//1 3//1 4//1\n"          # quad, equal diagonals -> (0,1,3),(1,2,3)
+                 "f -5 -4 -3\n"                     # negative indices
+                 "f 1 2 3 5 4\n")                   # pentagon -> 3 triangles
+    s = host.SceneGeometry([str(p)])
+    assert s.ranges[0][2] == 2 + 1 + 3
+    assert list(s.idx[:9]) == [0, 1, 3, 1, 2, 3, 0, 1, 2]
+    assert sorted(set(s.idx[9:].tolist())) == [0, 1, 2, 3, 4]
+    q = tmp_path / "bad.obj"
+    q.write_text("v 0 0 0\nf 0 1 2\n")
+    with pytest.raises(RuntimeError):
+        host.SceneGeometry([str(q)])
+    with pytest.raises(RuntimeError):
+        host.SceneGeometry([str(tmp_path / "missing.obj")])
+
+
+def test_jpeg_decoder_matches_reference_decoder_golden(resources):
+    """host/jpeg_decode.cpp == stbi_load(..., STBI_rgb_alpha) byte for byte on all shipped faces
+    (baseline 4:2:0 `sea`, progressive 4:4:4 `test`)."""
+    g = json.load(open(os.path.join(GOLD, "ingest_golden.json")))["jpg"]
+    for sky in ("skybox_texture_test", "skybox_texture_sea"):
+        for f in host.SKYBOX_FACES:
+            a = host.decode_jpeg(os.path.join(resources, sky, f + ".jpg"))
+            k = g[sky + "/" + f]
+            assert a.shape == (k["h"], k["w"], 4)
+            assert hashlib.sha256(a.tobytes()).hexdigest() == k["sha256"], (sky, f)
+    with pytest.raises(RuntimeError):
+        host.decode_jpeg(os.path.join(resources, "teapot.obj"))
+
+
+def test_camera_matches_reference_formulas():
+    """src/camera.cpp:8-25, 66-106."""
+    c = host.Camera()
+    v = c.vectors()
+    assert np.allclose(v["position"], [0, 0, 20]) and np.allclose(v["front"], [0, 0, -1], atol=1e-6)
+    assert np.allclose(v["right"], [1, 0, 0], atol=1e-6) and np.allclose(v["up"], [0, 1, 0], atol=1e-6)
+    assert abs(v["front"][0]) > 0  # cos(-pi/2) in float is ~ -4.4e-8, not 0 (SURVEY.md §8c trap 7)
+    c.move(host.FORWARD, 2.0); c.move(host.RIGHT, 1.0); c.move(host.UP, 0.5)
+    assert np.allclose(c.vectors()["position"], [1, 0.5, 18], atol=1e-5)
+    c.process_mouse_movement(0.3, 5.0)
+    v = c.vectors()
+    yaw, pitch = -np.pi / 2 + 0.3, 1.57  # pitch clamp
+    f = np.array([np.cos(yaw) * np.cos(pitch), np.sin(pitch), np.sin(yaw) * np.cos(pitch)])
+    assert np.allclose(v["front"], f, atol=1e-5)
+    r = np.array([-f[2], 0, f[0]]); r /= np.linalg.norm(r)
+    assert np.allclose(v["right"], r, atol=1e-5) and np.allclose(v["up"], np.cross(r, f), atol=1e-5)
+    c.look(host.LEFT)
+    assert np.allclose(c.vectors()["front"], [-1, 0, 0])
+    u = host.default_uniforms()
+    host.Camera((1, 2, 3)).to_uniforms(u)
+    assert np.allclose(u[0]["position"], [1, 2, 3, 1]) and u[0]["max_bounce_count"] == 63 and u[0]["samples_per_pixel"] == 4
+
+
+def test_animation_matches_restatement():
+    """src/main.cpp:1805-1808 and :2836-2844 vs the numpy restatement in oracle/ingest.py."""
+    a = host.SceneAnimation()
+    t = a.transforms()
+    assert np.array_equal(t[0], ingest.glm_to_vulkan(ingest.mat_identity()))
+    assert np.array_equal(t[1], ingest.glm_to_vulkan(ingest.mat_translate(ingest.mat_identity(), (0, 0, 5))))
+    m0 = ingest.mat_identity()
+    for k in range(1, 4):
+        a.animate(0.1 * k)
+        m0, m1 = ingest.animated_transforms(m0, 0.1 * k)
+        t = a.transforms()
+        assert np.allclose(t[0], ingest.glm_to_vulkan(m0), atol=1e-6) and np.allclose(t[1], ingest.glm_to_vulkan(m1), atol=1e-5)
+    inst = a.instances()
+    assert inst.dtype.itemsize == 64 and inst[1]["custom_index_and_mask"] == (1 | (0xFF << 24)) and inst[1]["mesh"] == 1
+
+
+def test_standin_mesh_is_deterministic_and_closed(tmp_path):
+    p = str(tmp_path / "s.obj")
+    assert host.hlib().rth_write_armadillo_standin(p.encode(), 6) == 0
+    s = host.SceneGeometry([p])
+    nv, nt = len(s.verts) // 6, s.ranges[0][2]
+    assert (nv, nt) == (10 * 36 + 2, 20 * 36)
+    # closed manifold: every edge shared by exactly two triangles
+    tri = s.idx.reshape(-1, 3)
+    e = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    assert np.all(counts == 2)
+    nrm = s.verts.reshape(-1, 6)[:, 3:6]
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-3)
+    assert (np.sum(nrm * s.verts.reshape(-1, 6)[:, 0:3], axis=1) > 0).all()  # outward
+    p2 = str(tmp_path / "s2.obj")
+    host.hlib().rth_write_armadillo_standin(p2.encode(), 6)
+    assert open(p).read() == open(p2).read()
+
+
+def test_band_sharding_covers_frame_once():
+    for H, band, n in ((1080, 8, 1), (1080, 8, 8), (1080, 8, 3), (203, 8, 2), (7, 8, 4), (2160, 8, 8)):
+        seen = np.zeros(H, int)
+        for s in range(n):
+            m = tiling.shard_row_map(H, band, s, n)
+            assert len(m) == tiling.shard_rows(H, band, s, n)
+            seen[m] += 1
+        assert np.all(seen == 1)
+        shards = []
+        full = np.random.default_rng(0).random((H, 5, 4)).astype(np.float32)
+        rows_max = tiling.max_shard_rows(H, band, n)
+        for s in range(n):
+            buf = np.zeros((rows_max, 5, 4), np.float32)
+            m = tiling.shard_row_map(H, band, s, n)
+            buf[: len(m)] = full[m]
+            shards.append(buf)
+        assert np.array_equal(tiling.assemble(shards, H, 5, band), full)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np, torch, torch.distributed as dist
+from vulkan_raytracing_amd import tiling
+from oracle import oracle, ingest
+from tests import scenes
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%(port)d", rank=rank, world_size=world)
+W, H, band = 96, 54, 8
+sp = scenes.two_object_scene(os.path.join(scenes.RES, "teapot.obj"), os.path.join(scenes.RES, "cube.obj"), 1, 0, 1, 1, sky=scenes.synthetic_skybox(16))
+# each rank renders ONLY its bands (the oracle stands in for the GPU renderer in this CPU rehearsal)
+rows = tiling.shard_row_map(H, band, rank, world)
+rows_max = tiling.max_shard_rows(H, band, world)
+shard = torch.zeros((rows_max, W, 4))
+for y in rows.reshape(-1, 1) if len(rows) else []:
+    img, _ = sp.orc.render(W, H, y0=int(y[0]), y1=int(y[0]) + 1, threads=1)
+    shard[int(np.where(rows == y[0])[0][0])] = torch.from_numpy(img[int(y[0])])
+gl = [torch.zeros_like(shard) for _ in range(world)] if rank == 0 else None
+dist.gather(shard, gl, dst=0)
+if rank == 0:
+    out = tiling.assemble([g.numpy() for g in gl], H, W, band)
+    full, _ = sp.orc.render(W, H, threads=2)
+    assert np.array_equal(out, full), "gathered frame differs from the single-process frame"
+    print("GLOO_OK")
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gather_reassembles_frame_gloo(tmp_path):
+    """World-size-2 rehearsal of bench.py's N > 1 path on CPU: band sharding -> gather -> assemble."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    script = tmp_path / "w.py"
+    script.write_text(_GLOO_WORKER % {"root": ROOT, "port": port})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1")
+        procs.append(subprocess.Popen(["python", str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "GLOO_OK" in outs[0]

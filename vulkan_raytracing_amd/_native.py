@@ -26,6 +26,14 @@ def _load(name, make_target):
 
 
 def load_rt():
+    # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
+    # Two HIP/HSA runtimes cannot share one process, so when torch is installed it is imported FIRST:
+    # librt_mi355x.so's DT_NEEDED libamdhip64.so.7 then binds to the copy torch already loaded and the
+    # tensors handed to rt_trace_shard live in the same runtime as the kernels that fill them.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     return _load("librt_mi355x.so", "vulkan_raytracing_amd/librt_mi355x.so")
 
 

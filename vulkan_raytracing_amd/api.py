@@ -18,7 +18,8 @@ assert INSTANCE_DTYPE.itemsize == 64 and UNIFORMS_DTYPE.itemsize == 104 and MESH
 
 class RtStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
-                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("closest_rays", C.c_uint64),
+                ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("node_visits_shadow", C.c_uint64), ("tri_tests_shadow", C.c_uint64),
+                ("closest_rays", C.c_uint64),
                 ("ms_frame", C.c_float), ("ms_raygen", C.c_float), ("ms_trace_closest", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_shade", C.c_float), ("ms_resolve", C.c_float),
                 ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32),

@@ -71,3 +71,23 @@ void rth_camera_to_uniforms(void* c, rt_uniforms* u) {
 }
 
 }  // extern "C"
+
+// ---- skybox faces: rtjpeg (host/jpeg_decode.cpp) ---------------------------------------------------
+#include <cstdlib>
+
+#include "jpeg_decode.h"
+extern "C" {
+int rth_decode_jpeg(const char* path, void** rgba, int* w, int* h, char* err, int errlen) {
+  rtjpeg::Image img; std::string e;
+  if (!rtjpeg::decode_file(path, img, e)) {
+    if (err && errlen > 0) { strncpy(err, e.c_str(), (size_t)errlen - 1); err[errlen - 1] = 0; }
+    return 1;
+  }
+  void* p = malloc(img.rgba.size());
+  if (!p) return 2;
+  memcpy(p, img.rgba.data(), img.rgba.size());
+  *rgba = p; *w = img.w; *h = img.h;
+  return 0;
+}
+void rth_free(void* p) { free(p); }
+}

@@ -347,8 +347,9 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
       cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
     }
     if (lane == 0) {
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS), (unsigned long long)cnt_nodes);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS), (unsigned long long)cnt_tris);
+      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
     }
   }
 }

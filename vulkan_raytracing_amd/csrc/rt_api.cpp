@@ -309,6 +309,8 @@ int collect_stats(rt_ctx* c) {
   st.closest_rays = st.rays_primary + st.rays_secondary;
   memcpy(&st.node_visits, &cnt[CNT_NODE_VISITS], 8);
   memcpy(&st.tri_tests, &cnt[CNT_TRI_TESTS], 8);
+  memcpy(&st.node_visits_shadow, &cnt[CNT_NODE_VISITS_SH], 8);
+  memcpy(&st.tri_tests_shadow, &cnt[CNT_TRI_TESTS_SH], 8);
   st.bvh_node_bytes = sizeof(BvhNode); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
     float ms = 0.f;
@@ -567,8 +569,8 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
   if (stats) {
     uint32_t cnt[CNT_WORDS];
     HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
-    memcpy(&stats->node_visits, &cnt[CNT_NODE_VISITS], 8);
-    memcpy(&stats->tri_tests, &cnt[CNT_TRI_TESTS], 8);
+    memcpy(&stats->node_visits, &cnt[any_hit ? CNT_NODE_VISITS_SH : CNT_NODE_VISITS], 8);
+    memcpy(&stats->tri_tests, &cnt[any_hit ? CNT_TRI_TESTS_SH : CNT_TRI_TESTS], 8);
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     if (any_hit) stats->ms_trace_shadow = ms; else stats->ms_trace_closest = ms;
     stats->closest_rays = any_hit ? 0 : n; stats->rays_shadow = any_hit ? n : 0;

@@ -63,8 +63,10 @@ enum : int {
   CNT_SHADOW = 0,        // shadow-queue tail = number of shadow rays
   CNT_QUEUE0 = 1,        // CNT_QUEUE0 + b = rays in the queue of bounce b (b = 0: primary, incl. dead pads)
   CNT_MAX_BOUNCES = 72,
-  CNT_NODE_VISITS = 80,  // uint64 at [80,81]   (counting kernels only)
+  CNT_NODE_VISITS = 80,  // uint64 at [80,81]   closest-hit kernel (counting builds only)
   CNT_TRI_TESTS = 82,    // uint64 at [82,83]
+  CNT_NODE_VISITS_SH = 84,  // uint64: any-hit (shadow) kernel
+  CNT_TRI_TESTS_SH = 86,
   CNT_WORDS = 96
 };
 
