@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (kernel-trace --stats, and --pmc passes) into a small text summary
+that is committed under profiles/.  Usage: summarize_profile.py <dir> [--json out.json]"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name
+    for a, b in (("rt::", ""), ("void ", "")):
+        n = n.replace(a, b)
+    return n[:70]
+
+
+def kernel_stats(d):
+    rows = []
+    for f in glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            rows.append(r)
+    return rows
+
+
+def kernel_trace(d):
+    per = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            per[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return per
+
+
+def pmc(d):
+    out = defaultdict(lambda: defaultdict(list))
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return out
+
+
+def main():
+    base = sys.argv[1]
+    res = {}
+    print("== rocprofv3 --kernel-trace --stats (%s/trace) ==" % base)
+    st = kernel_stats(os.path.join(base, "trace"))
+    for r in sorted(st, key=lambda r: -float(r.get("TotalDurationNs", 0) or 0)):
+        print("%-72s calls %6s  total %10.1f us  avg %9.2f us  %5s%%" % (short(r["Name"]), r["Calls"], float(r["TotalDurationNs"]) / 1e3,
+                                                                       float(r["AverageNs"]) / 1e3, r.get("Percentage", "")))
+    tr = kernel_trace(os.path.join(base, "trace"))
+    res["avg_us"] = {short(k): sum(v) / len(v) for k, v in tr.items()}
+    for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", None)):
+        p = pmc(os.path.join(base, tag))
+        if not p:
+            continue
+        print("== PMC pass %s ==" % tag)
+        for k, cs in p.items():
+            line = "%-72s" % short(k)
+            for c, v in cs.items():
+                line += "  %s avg %.4g (n=%d)" % (c, sum(v) / len(v), len(v))
+                res.setdefault("pmc", {}).setdefault(short(k), {})[c] = sum(v) / len(v)
+            print(line)
+    # HBM traffic per launch of the closest-hit traversal kernel (gfx950 correction of
+    # MI355X_MICROARCH.md §HBM: FETCH_SIZE is in KiB of 64-B requests and reads HALF the bytes of a wide
+    # coalesced stream; WRITE_SIZE is exact) — both bounds are reported.
+    pm = res.get("pmc", {})
+    for k in pm:
+        if "k_trace<0" in k and "FETCH_SIZE" in pm[k]:
+            fetch_kib = pm[k]["FETCH_SIZE"]
+            write_kib = pm[k].get("WRITE_SIZE", 0.0)
+            lo = (fetch_kib + write_kib) * 1024.0
+            hi = (2.0 * fetch_kib + write_kib) * 1024.0
+            res["hbm_bytes_per_launch_uncorrected"] = lo
+            res["hbm_bytes_per_launch"] = hi
+            print("closest-hit traversal: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB per launch -> HBM bytes/launch %.3e (x2 read correction) / %.3e (raw)" % (fetch_kib, write_kib, hi, lo))
+    if "--json" in sys.argv:
+        json.dump(res, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
