@@ -88,6 +88,7 @@ typedef struct rt_stats {
   uint64_t tri_tests;
   uint64_t node_visits_shadow; /* any-hit kernel, same */
   uint64_t tri_tests_shadow;
+  uint64_t diag[6];          /* counting build: loop trips, busy quad-trips, wave cycles (closest; shadow) */
   uint64_t closest_rays;     /* rays through the closest-hit traversal kernel (primary+secondary) */
   float ms_frame;            /* HIP-event time of the whole frame pipeline on the trace stream */
   float ms_raygen;
@@ -146,6 +147,10 @@ int rt_synchronize(rt_ctx* ctx);
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
 /* Enable per-kernel hipEvent timing (adds event records to the stream; default off). */
 int rt_set_timing(rt_ctx* ctx, int enabled);
+
+/* Tunables (no reference counterpart): "trace_variant" 1 = BVH4 / four lanes per ray (default), 0 = BVH2 /
+ * one lane per ray; "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16.  Results do not depend on them. */
+int rt_set_param(rt_ctx* ctx, const char* name, int value);
 
 /* Record-level entry for traceRayEXT alone (rows a10/a14): n rays of 8 floats (o.xyz, tmin, d.xyz, tmax)
  * from host memory; any_hit!=0 = TerminateOnFirstHit|SkipClosestHit (src/shader.rgen:67). Blocking.

@@ -19,14 +19,14 @@ assert INSTANCE_DTYPE.itemsize == 64 and UNIFORMS_DTYPE.itemsize == 104 and MESH
 class RtStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_secondary", C.c_uint64), ("rays_shadow", C.c_uint64),
                 ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64), ("node_visits_shadow", C.c_uint64), ("tri_tests_shadow", C.c_uint64),
-                ("closest_rays", C.c_uint64),
+                ("diag", C.c_uint64 * 6), ("closest_rays", C.c_uint64),
                 ("ms_frame", C.c_float), ("ms_raygen", C.c_float), ("ms_trace_closest", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_shade", C.c_float), ("ms_resolve", C.c_float),
                 ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32),
                 ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_}
+        return {k: (list(getattr(self, k)) if k == "diag" else getattr(self, k)) for k, _ in self._fields_}
 
     @property
     def rays_total(self):
@@ -35,7 +35,7 @@ class RtStats(C.Structure):
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
            "rt_trace", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
-           "rt_trace_counting", "rt_last_error", "rt_device_info", "rt_abi_version"]
+           "rt_trace_counting", "rt_set_param", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
 _LIB = None
 
@@ -60,6 +60,7 @@ def lib():
         L.rt_synchronize.argtypes = [vp]
         L.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
         L.rt_set_timing.argtypes = [vp, C.c_int]
+        L.rt_set_param.argtypes = [vp, C.c_char_p, C.c_int]
         L.rt_intersect.argtypes = [vp, C.c_size_t, vp, C.c_int, vp, C.c_int, C.POINTER(RtStats)]
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p
@@ -165,6 +166,9 @@ class RtContext:
 
     def set_timing(self, on):
         self._chk(self.L.rt_set_timing(self.h, int(on)), "rt_set_timing")
+
+    def set_param(self, name, value):
+        self._chk(self.L.rt_set_param(self.h, name.encode(), int(value)), "rt_set_param")
 
     def intersect(self, rays8, any_hit=False, counting=False):
         rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)

@@ -215,6 +215,93 @@ void refit_bvh(const Aabb* prim_boxes, BuiltBvh& bvh) {
   if (bvh.topo[0].left < 0) set_child_box(bvh.nodes[0], 0, bvh.topo[0].box);
 }
 
+// ---------------------------------------------------------------------------------------------
+namespace {
+inline void set_child4(Bvh4Child& c, const Aabb& b, int32_t ref) {
+  c.lo[0] = b.lo[0]; c.lo[1] = b.lo[1]; c.lo[2] = b.lo[2];
+  c.hix = b.hi[0]; c.hiy = b.hi[1]; c.hiz = b.hi[2];
+  c.ref = ref; c.pad = 0;
+}
+struct Collapser {
+  const BuiltBvh* b2; Bvh4* out; bool area_driven, direct_ids;
+  int32_t leaf_ref(const BuildNode& t) const {
+    if (direct_ids) return ~(int32_t)b2->order[t.first];
+    return ~(int32_t)((t.first << 3) | (t.count - 1));
+  }
+  // worst case of the traversal stack below node e: all k children hit -> k-1 pushed while inside one
+  int stack_need(int32_t e) const {
+    int k = 0, deepest = 0;
+    for (int c = 0; c < 4; c++) {
+      const int32_t ref = out->nodes[e].c[c].ref;
+      if (ref == 0x7FFFFFFF) continue;
+      k++;
+      if (ref >= 0) deepest = std::max(deepest, stack_need(ref));
+    }
+    return std::max(0, k - 1) + deepest;
+  }
+  int32_t emit(int ti, int depth) {
+    out->depth = std::max(out->depth, depth);
+    int kids[4]; int nk = 2;
+    kids[0] = b2->topo[ti].left; kids[1] = b2->topo[ti].right;
+    while (nk < 4) {
+      int pick = -1; float best = -1.f;
+      for (int k = 0; k < nk; k++) {
+        const BuildNode& c = b2->topo[kids[k]];
+        if (c.left < 0) continue;
+        if (!area_driven) { pick = k; break; }
+        float a = half_area(c.box);
+        if (a > best) { best = a; pick = k; }
+      }
+      if (pick < 0) break;
+      const BuildNode& c = b2->topo[kids[pick]];
+      for (int k = nk; k > pick + 1; k--) kids[k] = kids[k - 1];
+      kids[pick + 1] = c.right; kids[pick] = c.left;
+      nk++;
+    }
+    int32_t e = (int32_t)out->nodes.size();
+    out->nodes.push_back(Bvh4Node{});
+    out->child_topo.resize(out->child_topo.size() + 4, -1);
+    for (int k = 0; k < 4; k++) {
+      if (k < nk) {
+        const BuildNode& c = b2->topo[kids[k]];
+        out->child_topo[4 * (size_t)e + k] = kids[k];
+        int32_t ref = c.left < 0 ? leaf_ref(c) : emit(kids[k], depth + 1);
+        set_child4(out->nodes[e].c[k], c.box, ref);
+      } else {
+        set_child4(out->nodes[e].c[k], missing_box(), 0x7FFFFFFF);
+      }
+    }
+    return e;
+  }
+};
+}  // namespace
+
+void collapse_bvh4(const BuiltBvh& b2, bool area_driven, bool direct_ids, Bvh4& out) {
+  out = Bvh4{};
+  Collapser c{&b2, &out, area_driven, direct_ids};
+  if (b2.topo.empty() || b2.topo[0].left < 0) {
+    Bvh4Node root{};
+    out.child_topo.assign(4, -1);
+    for (int k = 0; k < 4; k++) set_child4(root.c[k], missing_box(), 0x7FFFFFFF);
+    if (!b2.topo.empty()) { set_child4(root.c[0], b2.topo[0].box, c.leaf_ref(b2.topo[0])); out.child_topo[0] = 0; }
+    out.nodes.push_back(root);
+    return;
+  }
+  c.emit(0, 0);
+  out.stack_need = c.stack_need(0);
+}
+
+void refit_bvh4(const BuiltBvh& b2, Bvh4& b4) {
+  for (size_t e = 0; e < b4.nodes.size(); e++)
+    for (int k = 0; k < 4; k++) {
+      int32_t t = b4.child_topo[4 * e + k];
+      if (t < 0) continue;
+      const Aabb& b = b2.topo[t].box;
+      Bvh4Child& c = b4.nodes[e].c[k];
+      c.lo[0] = b.lo[0]; c.lo[1] = b.lo[1]; c.lo[2] = b.lo[2]; c.hix = b.hi[0]; c.hiy = b.hi[1]; c.hiz = b.hi[2];
+    }
+}
+
 void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris) {
   std::vector<Aabb> boxes(n_prims);
   for (uint32_t p = 0; p < n_prims; p++) {

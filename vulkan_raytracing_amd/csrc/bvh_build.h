@@ -37,6 +37,20 @@ void build_bvh(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, 
 // rewrite bvh.nodes in place.
 void refit_bvh(const Aabb* prim_boxes, BuiltBvh& bvh);
 
+// BVH4 obtained by collapsing a BuiltBvh (children of a node = up to 4 subtrees of the BVH2).
+struct Bvh4 {
+  std::vector<Bvh4Node> nodes;                    // node 0 = root
+  std::vector<int32_t> child_topo;                // 4 per node: BuildNode index of each child or -1
+  int depth = 0;
+  int stack_need = 0;   // worst-case number of stack entries the quad traversal can hold inside this tree
+};
+// area_driven: expand the child with the largest surface area first (BLAS); otherwise expand in
+// order, which makes the topology independent of the boxes (TLAS: refit keeps it).
+// direct_ids: leaves hold ~primitive (TLAS instances) instead of ~((first << 3) | (count - 1)).
+void collapse_bvh4(const BuiltBvh& b2, bool area_driven, bool direct_ids, Bvh4& out);
+// rewrite the child boxes of b4 from b2.topo (after refit_bvh)
+void refit_bvh4(const BuiltBvh& b2, Bvh4& b4);
+
 // BLAS helper: boxes + 48-byte packets for an indexed triangle mesh in the reference's layout
 // (positions at verts6[6*i .. 6*i+2], object-local uint32 indices).
 void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris);

@@ -120,238 +120,42 @@ __device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter) {
   return base + prefix_rank(mask);
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_raygen: one thread per (8x8 pixel tile, sample, lane).  src/shader.rgen:62-79.
-__global__ __launch_bounds__(256) void k_raygen(FrameDev f, UniformsDev u) {
-  const uint32_t tiles_x = ((uint32_t)f.width + 7u) >> 3;
-  const uint32_t tiles_y = ((uint32_t)f.rows + 7u) >> 3;
-  const uint32_t spp = u.samples_per_pixel;
-  const uint32_t total = tiles_x * tiles_y * spp * 64u;
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q == 0) f.counters[CNT_QUEUE0] = total;
-  if (q >= total) return;
-  const uint32_t lane = q & 63u;
-  const uint32_t ts = q >> 6;
-  const uint32_t i = ts % spp;
-  const uint32_t tile = ts / spp;
-  const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u);
-  const uint32_t ly = (tile / tiles_x) * 8u + (lane >> 3);
-  if (x >= (uint32_t)f.width || ly >= (uint32_t)f.rows) {
-    f.ray_o[0][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-    f.ray_d[0][q] = make_float4(0.f, 0.f, 1.f, __uint_as_float(SID_DEAD));
-    return;
-  }
-  const uint32_t band = ly / (uint32_t)f.band_rows;
-  const uint32_t y = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + (ly % (uint32_t)f.band_rows);
-  const float fx = (float)x, fy = (float)y;
-  const float seed0 = (float)(spp + i), seed1 = seed0 + 0.5f;
-  float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)f.width;
-  float uy = (fy + jitter_hash(fx, fy, seed1)) / (float)f.height;
-  ux = __builtin_fmaf(ux, 2.0f, -1.0f);
-  uy = -__builtin_fmaf(uy, 2.0f, -1.0f);
-  F3 right = mk3(u.right[0], u.right[1], u.right[2]), up = mk3(u.up[0], u.up[1], u.up[2]), fwd = mk3(u.forward[0], u.forward[1], u.forward[2]);
-  F3 d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
-  const uint32_t sid = i * (uint32_t)(f.rows * f.width) + ly * (uint32_t)f.width + x;
-  f.ray_o[0][q] = make_float4(u.position[0], u.position[1], u.position[2], 10000.0f);
-  f.ray_d[0][q] = make_float4(d.x, d.y, d.z, __uint_as_float(sid));
-}
-
-// ------------------------------------------------------------------------------------------------
-// Traversal.  Two-level BVH2, one ray per lane, per-wave LDS stack [entry][lane] (bank = lane, so
-// pushes/pops never conflict), spill to HBM above STACK_LDS entries.
-struct TraceArgs {
-  SceneDev sc;
-  const float4* ray_o;
-  const float4* ray_d;
-  const uint32_t* n_ptr;
-  // closest-hit pipeline outputs
-  float4* hit_a;
-  int32_t* hit_inst;
-  // shadow pipeline
-  const float4* sh_c;
-  float4* sample_color;
-  // raw mode
-  HitRec* raw_out;
-  int32_t* ovf_stack;
-  uint32_t* counters;
-  float tmin;
-};
-
-constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
-constexpr int MODE_SHADOW = 1;   // pipeline any hit + shading epilogue
-constexpr int MODE_RAW = 2;      // o.w = tmin, d.w = tmax; writes HitRec
-constexpr int STACK_MARK = 0x7FFFFFFE;  // "return to world space" marker
-
 __device__ __forceinline__ float safe_rcp(float d) {
   const float eps = 1e-20f;
   float a = __builtin_fabsf(d) < eps ? __builtin_copysignf(eps, d) : d;
   return __builtin_amdgcn_rcpf(a);
 }
 
-template <int MODE, bool ANY, bool COUNT>
-__global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
-  __shared__ int s_stack[4][STACK_LDS][64];
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  int(*stk)[64] = s_stack[wave];
-  int32_t* ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * STACK_OVF;
-  const uint32_t n = *a.n_ptr;
-  const uint32_t n_waves = gridDim.x * 4u;
-  uint64_t cnt_nodes = 0, cnt_tris = 0;
+// Conservative slab test of one box (box tests need not be bit-reproducible, only never to reject a
+// box the canonical triangle test would hit: sub-mul form, relative slack 2^-15.6).
+__device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix, float hiy, float hiz, F3 o, F3 id, float tmin, float tlim, float& tn) {
+  float x0 = (lox - o.x) * id.x, x1 = (hix - o.x) * id.x;
+  float y0 = (loy - o.y) * id.y, y1 = (hiy - o.y) * id.y;
+  float z0 = (loz - o.z) * id.z, z1 = (hiz - o.z) * id.z;
+  tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+  float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tlim));
+  return tn <= tf * 1.00002f;
+}
 
-  for (uint32_t base = (blockIdx.x * 4u + wave) * 64u; base < n; base += n_waves * 64u) {
-    const uint32_t q = base + lane;
-    bool active = q < n;
-    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (active) { ro = a.ray_o[q]; rd = a.ray_d[q]; }
-    float tmin, tmax;
-    uint32_t sid = 0;
-    if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
-    else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); if (sid == SID_DEAD) active = false; }
-
-    // world-space ray (kept for the return from an instance) and current-space ray
-    const F3 wo = mk3(ro.x, ro.y, ro.z), wd = mk3(rd.x, rd.y, rd.z);
-    F3 co = wo, cd = wd;
-    F3 id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
-    float best_t = tmax, best_u = 0.f, best_v = 0.f;
-    int best_prim = -1, best_inst = -1;
-    int cur_inst = -1;
-    const BvhNode* nodes = a.sc.tlas_nodes;
-    int sp = 0;
-    int cur = 0;               // TLAS root (always interior)
-    bool done = !active;
-
-    auto push = [&](int v) {
-      if (sp < STACK_LDS) stk[sp][lane] = v; else ovf[sp - STACK_LDS] = v;
-      sp++;
-    };
-    auto pop = [&]() {
-      for (;;) {
-        if (sp == 0) { done = true; return; }
-        sp--;
-        cur = (sp < STACK_LDS) ? stk[sp][lane] : ovf[sp - STACK_LDS];
-        if (cur != STACK_MARK) return;
-        // leave the instance: back to the world-space ray and the TLAS
-        co = wo; cd = wd;
-        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
-        nodes = a.sc.tlas_nodes; cur_inst = -1;
-      }
-    };
-
-    while (!done) {
-      if (cur >= 0) {
-        // ---- interior node: 56 useful bytes of one 64-byte record
-        const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-        const float4 A = np[0], B = np[1], C = np[2];
-        const int2 ch = *reinterpret_cast<const int2*>(np + 3);
-        if (COUNT) cnt_nodes++;
-        const float lim = best_t;
-        float t0, t1;
-        bool h0, h1;
-        {
-          float x0 = (A.x - co.x) * id.x, x1 = (A.y - co.x) * id.x;
-          float y0 = (A.z - co.y) * id.y, y1 = (A.w - co.y) * id.y;
-          float z0 = (C.x - co.z) * id.z, z1 = (C.y - co.z) * id.z;
-          float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-          float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
-          h0 = tn <= tf * 1.00002f; t0 = tn;
-        }
-        {
-          float x0 = (B.x - co.x) * id.x, x1 = (B.y - co.x) * id.x;
-          float y0 = (B.z - co.y) * id.y, y1 = (B.w - co.y) * id.y;
-          float z0 = (C.z - co.z) * id.z, z1 = (C.w - co.z) * id.z;
-          float tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-          float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
-          h1 = tn <= tf * 1.00002f; t1 = tn;
-        }
-        if (h0 && h1) {
-          const bool swap = t1 < t0;
-          push(swap ? ch.x : ch.y);
-          cur = swap ? ch.y : ch.x;
-        } else if (h0) cur = ch.x;
-        else if (h1) cur = ch.y;
-        else pop();
-      } else if (cur_inst < 0) {
-        // ---- TLAS leaf: enter an instance (ray -> object space, t preserved)
-        const int ii = ~cur;
-        const InstanceDev* I = a.sc.inst + ii;
-        if ((I->mask & 0xFFu) == 0u) { pop(); continue; }
-        float m[12];
-        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
-        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
-        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
-        co = xform_point(m, wo); cd = xform_vec(m, wd);
-        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
-        push(STACK_MARK);
-        cur_inst = ii; nodes = a.sc.blas_nodes; cur = I->blas_root;
-      } else {
-        // ---- BLAS leaf: Möller–Trumbore on 48-byte packets (canonical form, see oracle tri_test)
-        const uint32_t ref = (uint32_t)(~cur);
-        const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-          const float4* tp = a.sc.tris + (size_t)(first + k) * 3;
-          const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
-          if (COUNT) cnt_tris++;
-          const F3 v0 = mk3(T0.x, T0.y, T0.z), e1 = mk3(T0.w, T1.x, T1.y), e2 = mk3(T1.z, T1.w, T2.x);
-          const F3 p = cross3(cd, e2);
-          const float det = dot3(e1, p);
-          const F3 s = sub3(co, v0);
-          float un = dot3(s, p);
-          const F3 qv = cross3(s, e1);
-          float vn = dot3(cd, qv);
-          float tn = dot3(e2, qv);
-          const float da = __builtin_fabsf(det);
-          if (det < 0.0f) { un = -un; vn = -vn; tn = -tn; }
-          if ((un >= 0.0f) && (vn >= 0.0f) && (un + vn <= da) && (da > 0.0f)) {
-            const float inv = 1.0f / da;
-            const float tt = tn * inv;
-            if ((tt > tmin) && (tt < tmax)) {
-              const int prim = (int)__float_as_uint(T2.y);
-              const bool better = (best_inst < 0) || (tt < best_t) ||
-                                  (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
-              if (better) { best_t = tt; best_u = un * inv; best_v = vn * inv; best_prim = prim; best_inst = cur_inst; }
-            }
-          }
-        }
-        if (ANY && best_inst >= 0) { done = true; }
-        else pop();
-      }
-    }
-
-    // ---- epilogue
-    if (MODE == MODE_CLOSEST) {
-      if (q < n) {
-        a.hit_a[q] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
-        a.hit_inst[q] = best_inst;
-      }
-    } else if (MODE == MODE_SHADOW) {
-      if (active) {
-        // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
-        const float4 c = a.sh_c[q];
-        float r = 0.08f, g = 0.24f, b = 0.08f;
-        if (best_inst < 0) { r = __builtin_fmaf(c.w, c.x, r); g = __builtin_fmaf(c.w, c.y, g); b = __builtin_fmaf(c.w, c.z, b); }
-        a.sample_color[sid] = make_float4(r, g, b, 1.0f);
-      }
-    } else {
-      if (q < n) {
-        HitRec h;
-        h.t = best_t; h.u = best_u; h.v = best_v; h.prim = best_prim; h.inst = best_inst;
-        a.raw_out[q] = h;
-      }
-    }
-  }
-  if (COUNT) {
-    // wave-reduce then one atomic per wave
-    for (int off = 32; off > 0; off >>= 1) {
-      cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
-      cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
-    }
-    if (lane == 0) {
-      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
-    }
-  }
+// Canonical Moller-Trumbore on one 48-byte packet (see oracle tri_test): two-sided, division-free
+// rejection, one IEEE reciprocal for an accepted candidate, accept iff tmin < t < tmax.
+__device__ __forceinline__ bool tri_test(const float4 T0, const float4 T1, const float4 T2, F3 co, F3 cd, float tmin, float tmax, float& t, float& u, float& v) {
+  const F3 v0 = mk3(T0.x, T0.y, T0.z), e1 = mk3(T0.w, T1.x, T1.y), e2 = mk3(T1.z, T1.w, T2.x);
+  const F3 p = cross3(cd, e2);
+  const float det = dot3(e1, p);
+  const F3 s = sub3(co, v0);
+  float un = dot3(s, p);
+  const F3 qv = cross3(s, e1);
+  float vn = dot3(cd, qv);
+  float tn = dot3(e2, qv);
+  const float da = __builtin_fabsf(det);
+  if (det < 0.0f) { un = -un; vn = -vn; tn = -tn; }
+  if (!((un >= 0.0f) && (vn >= 0.0f) && (un + vn <= da) && (da > 0.0f))) return false;
+  const float inv = 1.0f / da;
+  const float tt = tn * inv;
+  if (!((tt > tmin) && (tt < tmax))) return false;
+  t = tt; u = un * inv; v = vn * inv;
+  return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -381,7 +185,473 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_shade: closest-hit / miss shading and path continuation for one bounce.
+// k_raygen: one thread per (8x8 pixel tile, sample, lane).  src/shader.rgen:62-79, fused with the
+// first step every traceRayEXT performs: the ray is tested against the boxes of the TLAS root.  A
+// ray that enters none of them is a miss (src/shader.rmiss:11), so its sky colour
+// (src/shader.rgen:90-94) is written here and it never touches a queue; the survivors are compacted
+// into bounce queue 0 (shard blockIdx % 8) with a wavefront ballot.  On the headline frame ~80 % of
+// the primary rays end here, which removes their ray/hit records from HBM traffic altogether.
+__global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u) {
+  const uint32_t tiles_x = ((uint32_t)f.width + 7u) >> 3;
+  const uint32_t tiles_y = ((uint32_t)f.rows + 7u) >> 3;
+  const uint32_t spp = u.samples_per_pixel;
+  const uint32_t total = tiles_x * tiles_y * spp * 64u;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t lane = t & 63u;
+  const uint32_t ts = t >> 6;
+  const uint32_t i = ts % spp;
+  const uint32_t tile = ts / spp;
+  const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u);
+  const uint32_t ly = (tile / tiles_x) * 8u + (lane >> 3);
+  const bool live = t < total && x < (uint32_t)f.width && ly < (uint32_t)f.rows;
+  bool survive = false;
+  F3 d = mk3(0.f, 0.f, 1.f);
+  uint32_t sid = 0;
+  if (live) {
+    const uint32_t band = ly / (uint32_t)f.band_rows;
+    const uint32_t y = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + (ly % (uint32_t)f.band_rows);
+    const float fx = (float)x, fy = (float)y;
+    const float seed0 = (float)(spp + i), seed1 = seed0 + 0.5f;
+    float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)f.width;
+    float uy = (fy + jitter_hash(fx, fy, seed1)) / (float)f.height;
+    ux = __builtin_fmaf(ux, 2.0f, -1.0f);
+    uy = -__builtin_fmaf(uy, 2.0f, -1.0f);
+    F3 right = mk3(u.right[0], u.right[1], u.right[2]), up = mk3(u.up[0], u.up[1], u.up[2]), fwd = mk3(u.forward[0], u.forward[1], u.forward[2]);
+    d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
+    sid = i * (uint32_t)(f.rows * f.width) + ly * (uint32_t)f.width + x;
+    const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
+    const F3 id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+    const Bvh4Node* root = sc.nodes4 + sc.tlas_root4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const Bvh4Child& c = root->c[k];
+      float tn;
+      survive = survive || slab(c.lo[0], c.lo[1], c.lo[2], c.hix, c.hiy, c.hiz, o, id, 0.001f, 10000.0f, tn);
+    }
+    if (!survive) {
+      const F3 c = sample_sky(sc, mk3(d.x, d.y, -d.z));
+      f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
+    }
+  }
+  const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+  const uint32_t slot = wave_alloc(survive, f.counters + cnt_tail(0, (int)shard));
+  if (survive) {
+    const uint32_t v = shard * f.shard_cap + slot;
+    f.ray_o[0][v] = make_float4(u.position[0], u.position[1], u.position[2], 10000.0f);
+    f.ray_d[0][v] = make_float4(d.x, d.y, d.z, __uint_as_float(sid));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Traversal kernels.
+struct TraceArgs {
+  SceneDev sc;
+  const float4* ray_o;
+  const float4* ray_d;
+  const uint32_t* tails;       // counters + cnt_tail(queue, 0): entries per shard, CNT_STRIDE apart
+  uint32_t* work;              // counters + cnt_work(queue, 0): chunk cursors, CNT_STRIDE apart
+  uint32_t shard_cap;
+  float4* hit_a;               // closest-hit pipeline outputs
+  int32_t* hit_inst;
+  const float4* sh_c;          // shadow pipeline
+  float4* sample_color;
+  HitRec* raw_out;             // raw mode
+  int32_t* ovf_stack;
+  uint32_t* counters;
+  float tmin;
+};
+
+constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
+constexpr int MODE_SHADOW = 1;   // pipeline any hit + shading epilogue
+constexpr int MODE_RAW = 2;      // o.w = tmin, d.w = tmax; writes HitRec
+constexpr int STACK_MARK = 0x7FFFFFFE;  // "return to world space" marker (variant 0)
+
+// ---- variant 0: BVH2, one ray per lane, per-wave LDS stack [entry][lane] (kept as the A/B baseline
+// of the quad kernel; results are identical).  Batches of 64 rays, interleaved over the shards.
+template <int MODE, bool ANY, bool COUNT>
+__global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
+  __shared__ int s_stack[4][STACK_LDS][64];
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  int(*stk)[64] = s_stack[wave];
+  int32_t* ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * STACK_OVF;
+  uint32_t cnt[N_SHARDS], maxb = 0;
+#pragma unroll
+  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = a.tails[t * CNT_STRIDE]; maxb = max(maxb, (cnt[t] + 63u) >> 6); }
+  const uint32_t n_waves = gridDim.x * 4u;
+  uint64_t cnt_nodes = 0, cnt_tris = 0;
+
+  for (uint32_t g = blockIdx.x * 4u + wave; g < maxb * N_SHARDS; g += n_waves) {
+    const uint32_t shard = g & (N_SHARDS - 1), base = (g >> 3) << 6;
+    uint32_t n = 0;
+#pragma unroll
+    for (int t = 0; t < N_SHARDS; t++) n = (shard == (uint32_t)t) ? cnt[t] : n;
+    if (base >= n) continue;
+    const uint32_t q = shard * a.shard_cap + base + lane;
+    bool active = base + lane < n;
+    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
+    if (active) { ro = a.ray_o[q]; rd = a.ray_d[q]; }
+    float tmin, tmax;
+    uint32_t sid = 0;
+    if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
+    else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
+    const F3 wo = mk3(ro.x, ro.y, ro.z), wd = mk3(rd.x, rd.y, rd.z);
+    F3 co = wo, cd = wd;
+    F3 id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+    float best_t = tmax, best_u = 0.f, best_v = 0.f;
+    int best_prim = -1, best_inst = -1;
+    int cur_inst = -1;
+    const BvhNode* nodes = a.sc.tlas_nodes;
+    int sp = 0;
+    int cur = 0;               // TLAS root (always interior)
+    bool done = !active;
+
+    auto push = [&](int v) {
+      if (sp < STACK_LDS) stk[sp][lane] = v; else ovf[sp - STACK_LDS] = v;
+      sp++;
+    };
+    auto pop = [&]() {
+      for (;;) {
+        if (sp == 0) { done = true; return; }
+        sp--;
+        cur = (sp < STACK_LDS) ? stk[sp][lane] : ovf[sp - STACK_LDS];
+        if (cur != STACK_MARK) return;
+        co = wo; cd = wd;
+        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+        nodes = a.sc.tlas_nodes; cur_inst = -1;
+      }
+    };
+
+    while (!done) {
+      if (cur >= 0) {
+        const float4* np = reinterpret_cast<const float4*>(nodes + cur);
+        const float4 A = np[0], B = np[1], C = np[2];
+        const int2 ch = *reinterpret_cast<const int2*>(np + 3);
+        if (COUNT) cnt_nodes++;
+        float t0, t1;
+        const bool h0 = slab(A.x, A.z, C.x, A.y, A.w, C.y, co, id, tmin, best_t, t0);
+        const bool h1 = slab(B.x, B.z, C.z, B.y, B.w, C.w, co, id, tmin, best_t, t1);
+        if (h0 && h1) {
+          const bool swap = t1 < t0;
+          push(swap ? ch.x : ch.y);
+          cur = swap ? ch.y : ch.x;
+        } else if (h0) cur = ch.x;
+        else if (h1) cur = ch.y;
+        else pop();
+      } else if (cur_inst < 0) {
+        const int ii = ~cur;
+        const InstanceDev* I = a.sc.inst + ii;
+        if ((I->mask & 0xFFu) == 0u) { pop(); continue; }
+        float m[12];
+        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
+        co = xform_point(m, wo); cd = xform_vec(m, wd);
+        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+        push(STACK_MARK);
+        cur_inst = ii; nodes = a.sc.blas_nodes; cur = I->blas_root;
+      } else {
+        const uint32_t ref = (uint32_t)(~cur);
+        const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+          const float4* tp = a.sc.tris + (size_t)(first + k) * 3;
+          const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+          if (COUNT) cnt_tris++;
+          float tt, uu, vv;
+          if (tri_test(T0, T1, T2, co, cd, tmin, tmax, tt, uu, vv)) {
+            const int prim = (int)__float_as_uint(T2.y);
+            const bool better = (best_inst < 0) || (tt < best_t) ||
+                                (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
+            if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
+          }
+        }
+        if (ANY && best_inst >= 0) { done = true; }
+        else pop();
+      }
+    }
+
+    if (active) {
+      if (MODE == MODE_CLOSEST) {
+        a.hit_a[q] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
+        a.hit_inst[q] = best_inst;
+      } else if (MODE == MODE_SHADOW) {
+        const float4 c = a.sh_c[q];
+        float r = 0.08f, g2 = 0.24f, b = 0.08f;
+        if (best_inst < 0) { r = __builtin_fmaf(c.w, c.x, r); g2 = __builtin_fmaf(c.w, c.y, g2); b = __builtin_fmaf(c.w, c.z, b); }
+        a.sample_color[sid] = make_float4(r, g2, b, 1.0f);
+      } else {
+        HitRec h;
+        h.t = best_t; h.u = best_u; h.v = best_v; h.prim = best_prim; h.inst = best_inst;
+        a.raw_out[q] = h;
+      }
+    }
+  }
+  if (COUNT) {
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
+      cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
+    }
+    if (lane == 0) {
+      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
+    }
+  }
+}
+
+// ---- variant 1 (default): quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
+// 64-lane wavefront.
+//   * interior node (128 B, one cache line): lane k of the quad loads and tests child k (2 x dwordx4
+//     per lane, 4 consecutive 32-byte records per quad): one line look-up per ray and visit, and
+//     half as many dependent visits as the BVH2;
+//   * the four (hit, t_near) results are ranked inside the quad with DPP quad_perm moves — no LDS,
+//     no scalar loop; the nearest child becomes the next node, the others are written to the ray's
+//     LDS stack by their own lanes in far-to-near order;
+//   * leaf (<= 4 triangles): lane k runs Moller-Trumbore on triangle k, a quad-min picks the winner;
+//   * only 16 rays share a program counter, so incoherent rays lose far less to divergence;
+//   * persistent threads: each wave pulls 64-ray chunks from the sharded cursors, the chunk after
+//     next is already in flight into registers while the current one sits in LDS, and every quad
+//     that finishes a ray takes the next one from LDS at once (ballot + prefix rank) — no quad
+//     waits for its neighbours and no refill waits on HBM.
+// Control flow (cur, cur_inst, sp, need) is uniform within a quad, which keeps every DPP source lane
+// active.  Results are identical to k_trace: same triangle arithmetic, same tie rule.
+constexpr int QP_ROT1 = 0x39, QP_ROT2 = 0x4E, QP_ROT3 = 0x93, QP_SWAP1 = 0xB1, QP_SWAP2 = 0x4E;
+template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+}
+__device__ __forceinline__ uint32_t quad_or(uint32_t v) { v |= dpp_u<QP_SWAP1>(v); v |= dpp_u<QP_SWAP2>(v); return v; }
+__device__ __forceinline__ float quad_minf(float v) {
+  v = fminf(v, __uint_as_float(dpp_u<QP_SWAP1>(__float_as_uint(v))));
+  v = fminf(v, __uint_as_float(dpp_u<QP_SWAP2>(__float_as_uint(v))));
+  return v;
+}
+__device__ __forceinline__ int quad_mini(int v) {
+  v = min(v, (int)dpp_u<QP_SWAP1>((uint32_t)v));
+  v = min(v, (int)dpp_u<QP_SWAP2>((uint32_t)v));
+  return v;
+}
+
+constexpr int REF_DONE = (int)0x80000000;   // bottom-of-stack sentinel: the ray is finished
+constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both negative: not interior)
+
+template <int MODE, bool ANY, bool COUNT>
+__global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
+  __shared__ int s_stack[4][STACK4_LDS][16];                      // [wave][entry][ray]
+  __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];   // current chunk of each wave
+  __shared__ float4 s_world[4][2][16];                            // world-space ray of each quad
+  __shared__ float4 s_out[4][64];                                 // finished results, flushed in bursts
+  __shared__ int2 s_outq[4][64];                                  // (queue slot | sample id, instance)
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t sub = lane & 3u, ray = lane >> 2;
+  int(*stk)[16] = s_stack[wave];
+  const uint32_t KEY_MISS = 0xFFFFFFF0u;
+  const Bvh4Node* const nodes = a.sc.nodes4;   // BLAS nodes followed by the TLAS nodes: one base pointer
+  uint64_t cnt_nodes = 0, cnt_tris = 0;
+
+  // ---- work distribution (wave-uniform): prefetched chunk in registers, current chunk in LDS
+  uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
+  uint32_t pf_base = 0, pf_count = 0;
+  float4 pf_o = make_float4(0, 0, 0, 0), pf_d = pf_o, pf_c = pf_o;
+  uint32_t chunk_base = 0, chunk_count = 0, chunk_pos = 0;
+  auto prefetch = [&]() {
+    pf_count = 0;
+    while (tried < (uint32_t)N_SHARDS) {
+      const uint32_t size = a.tails[shard * CNT_STRIDE];
+      uint32_t off = 0;
+      if (lane == 0 && size) off = atomicAdd(a.work + shard * CNT_STRIDE, 64u);
+      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+      if (size && off < size) { pf_base = shard * a.shard_cap + off; pf_count = (size - off) < 64u ? (size - off) : 64u; break; }
+      shard = (shard + 1u) & (N_SHARDS - 1); tried++;
+    }
+    if (lane < pf_count) {
+      pf_o = a.ray_o[pf_base + lane]; pf_d = a.ray_d[pf_base + lane];
+      if (MODE == MODE_SHADOW) pf_c = a.sh_c[pf_base + lane];
+    }
+  };
+  auto promote = [&]() {
+    s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
+    if (MODE == MODE_SHADOW) s_rays[wave][2][lane] = pf_c;
+    chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
+    prefetch();
+  };
+  prefetch();
+  promote();
+
+  // ---- per-quad ray state (uniform within a quad)
+  bool need = true;
+  uint32_t q = 0, sid = 0;
+  float tmin = 0.f, tmax = 0.f;
+  F3 co = mk3(0, 0, 0), cd = mk3(0, 0, 1), id = mk3(1, 1, 1);
+  float4 shc = make_float4(0, 0, 0, 0);
+  float best_t = 0.f, best_u = 0.f, best_v = 0.f;
+  int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
+  uint64_t diag_iters = 0, diag_busy = 0;
+  const uint64_t diag_t0 = COUNT ? __builtin_readcyclecounter() : 0;
+  // Results are staged in LDS and written out in bursts of >= 48: stores share the wave's in-order
+  // vmcnt with the node loads, so a store per finished ray would stall the next node fetch every time.
+  uint32_t out_count = 0;
+  auto flush = [&]() {
+    if (lane < out_count) {
+      const float4 r = s_out[wave][lane];
+      const int2 k = s_outq[wave][lane];
+      if (MODE == MODE_CLOSEST) { a.hit_a[k.x] = r; a.hit_inst[k.x] = k.y; }
+      else if (MODE == MODE_SHADOW) a.sample_color[k.x] = r;
+      else { HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = (int)__float_as_uint(r.w); h.inst = k.y; a.raw_out[k.x] = h; }
+    }
+    out_count = 0;
+  };
+
+  for (;;) {
+    // ---- (A) refill: quads without a ray take the next rays of the LDS chunk
+    const uint64_t need_mask = __ballot(need);
+    if (need_mask != 0) {
+      if (chunk_pos == chunk_count && pf_count > 0) promote();
+      if (chunk_pos < chunk_count) {
+        const uint32_t rank = prefix_rank(need_mask) >> 2;   // needing quads before this one
+        const uint32_t want = (uint32_t)__builtin_popcountll(need_mask) >> 2;
+        const uint32_t avail = chunk_count - chunk_pos;
+        if (need && rank < avail) {
+          const uint32_t ci = chunk_pos + rank;
+          q = chunk_base + ci;
+          const float4 ro = s_rays[wave][0][ci], rd = s_rays[wave][1][ci];
+          if (MODE == MODE_SHADOW) shc = s_rays[wave][2][ci];
+          if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
+          else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
+          if (sub == 0) { s_world[wave][0][ray] = ro; s_world[wave][1][ray] = rd; }
+          co = mk3(ro.x, ro.y, ro.z); cd = mk3(rd.x, rd.y, rd.z);
+          id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+          best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
+          cur_inst = -1;
+          stk[0][ray] = REF_DONE; sp = 1;
+          cur = a.sc.tlas_root4;
+          need = false;
+        }
+        chunk_pos += want < avail ? want : avail;
+      } else if (need_mask == ~0ull) { flush(); break; }   // queue drained and every quad idle
+    }
+    do {   // phases B and C run only for quads that hold a ray; phase D below is wave-uniform
+    if (need) break;
+
+    // ---- (B) interior steps: stay in this loop while the quad's node is interior
+    while (cur >= 0) {
+      const float4* cp = reinterpret_cast<const float4*>(nodes + cur) + sub * 2u;
+      const float4 A = cp[0], B = cp[1];
+      if (COUNT) { if (sub == 0) cnt_nodes++; if (lane == 0) diag_iters++; }
+      float tn;
+      const bool hit = slab(A.x, A.y, A.z, A.w, B.x, B.y, co, id, tmin, best_t, tn);
+      const int ref = (int)__float_as_uint(B.z);
+      const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | sub) : (KEY_MISS | sub);
+      const uint32_t k1 = dpp_u<QP_ROT1>(key), k2 = dpp_u<QP_ROT2>(key), k3 = dpp_u<QP_ROT3>(key);
+      const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+      const int nh = (int)(k1 < KEY_MISS) + (int)(k2 < KEY_MISS) + (int)(k3 < KEY_MISS) + (int)hit;
+      const uint32_t nearest = quad_or((hit && rank == 0) ? (uint32_t)ref : 0u);
+      if (hit && rank > 0) stk[sp + nh - 1 - rank][ray] = ref;   // farthest child deepest
+      if (nh == 0) { sp--; cur = stk[sp][ray]; }
+      else { cur = (int)nearest; sp += nh - 1; }
+    }
+
+    // ---- (C) the node is not interior: finished, leave-instance marker, TLAS leaf or BLAS leaf
+    if (COUNT && lane == 0) { diag_busy++; }
+    if (cur == REF_DONE) {
+      // handled below at a wave-uniform point
+    } else if (cur == REF_MARK) {
+      // leave the instance: world-space ray back from LDS
+      const float4 ro = s_world[wave][0][ray], rd = s_world[wave][1][ray];
+      co = mk3(ro.x, ro.y, ro.z); cd = mk3(rd.x, rd.y, rd.z);
+      id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+      cur_inst = -1;
+      sp--; cur = stk[sp][ray];
+    } else if (cur_inst < 0) {
+      // TLAS leaf: enter the instance (all four lanes transform the same ray; t is preserved)
+      const int ii = ~cur;
+      const InstanceDev* I = a.sc.inst + ii;
+      if ((I->mask & 0xFFu) == 0u) { sp--; cur = stk[sp][ray]; }
+      else {
+        float m[12];
+        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
+        const F3 wo = co, wd = cd;
+        co = xform_point(m, wo); cd = xform_vec(m, wd);
+        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+        stk[sp][ray] = REF_MARK; sp++;
+        cur_inst = ii; cur = I->blas_root4;
+      }
+    } else {
+      // BLAS leaf: lane k tests triangle k
+      const uint32_t ref = (uint32_t)(~cur);
+      const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+      float tt = __builtin_inff(), uu = 0.f, vv = 0.f;
+      int prim = 0x7FFFFFFF;
+      if (sub < count) {
+        const float4* tp = a.sc.tris + (size_t)(first + sub) * 3;
+        const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+        if (COUNT) cnt_tris++;
+        float t1, u1, v1;
+        if (tri_test(T0, T1, T2, co, cd, tmin, tmax, t1, u1, v1)) { tt = t1; uu = u1; vv = v1; prim = (int)__float_as_uint(T2.y); }
+      }
+      const float tq = quad_minf(tt);
+      if (tq < __builtin_inff()) {
+        const int pq = quad_mini(tt == tq ? prim : 0x7FFFFFFF);
+        const bool better = (best_inst < 0) || (tq < best_t) ||
+                            (tq == best_t && (cur_inst < best_inst || (cur_inst == best_inst && pq < best_prim)));
+        if (better) {
+          const bool win = (tt == tq) && (prim == pq);
+          best_u = __uint_as_float(quad_or(win ? __float_as_uint(uu) : 0u));
+          best_v = __uint_as_float(quad_or(win ? __float_as_uint(vv) : 0u));
+          best_t = tq; best_prim = pq; best_inst = cur_inst;
+        }
+      }
+      if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
+      else { sp--; cur = stk[sp][ray]; }
+    }
+    } while (false);
+
+    // ---- (D) finished rays: append the result to the wave's LDS out-list, ask for new work
+    const bool fin = !need && cur == REF_DONE;
+    const uint64_t fin_mask = __ballot(fin);
+    if (fin_mask != 0) {
+      if (fin && sub == 0) {
+        const uint32_t slot = out_count + (prefix_rank(fin_mask) >> 2);
+        if (MODE == MODE_SHADOW) {
+          // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
+          float r = 0.08f, g = 0.24f, b = 0.08f;
+          if (best_inst < 0) { r = __builtin_fmaf(shc.w, shc.x, r); g = __builtin_fmaf(shc.w, shc.y, g); b = __builtin_fmaf(shc.w, shc.z, b); }
+          s_out[wave][slot] = make_float4(r, g, b, 1.0f);
+          s_outq[wave][slot] = make_int2((int)sid, 0);
+        } else {
+          s_out[wave][slot] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
+          s_outq[wave][slot] = make_int2((int)q, best_inst);
+        }
+      }
+      out_count += (uint32_t)__builtin_popcountll(fin_mask) >> 2;
+      if (fin) need = true;
+      if (out_count > 48u) flush();
+    }
+  }
+  if (COUNT) {
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
+      cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
+    }
+    if (lane == 0) {
+      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
+      // diagnostic build only: interior-loop trips, other-phase trips and cycles of this wave
+      const int dg = ANY ? CNT_DIAG_SH : CNT_DIAG;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg), (unsigned long long)diag_iters);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 2), (unsigned long long)diag_busy);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 4), (unsigned long long)(__builtin_readcyclecounter() - diag_t0));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_shade: closest-hit / miss shading and path continuation for one bounce.  Persistent grid; a wave
+// takes 64-entry batches interleaved over the shards and appends continuation / shadow rays to the
+// SAME shard with one wave-aggregated atomic each (wavefront ballot compaction).
 struct ShadeArgs {
   SceneDev sc;
   FrameDev f;
@@ -393,106 +663,114 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
   const FrameDev& f = a.f;
   const UniformsDev& U = a.u;
   const int cur = a.bounce & 1, nxt = cur ^ 1;
-  const uint32_t n = f.counters[CNT_QUEUE0 + a.bounce];
-  const uint32_t stride = gridDim.x * blockDim.x;
-  const uint32_t n_round = (n + 63u) & ~63u;  // whole waves stay together for the ballots
-  for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n_round; q += stride) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  uint32_t cnt[N_SHARDS], maxb = 0;
+#pragma unroll
+  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = f.counters[cnt_tail(a.bounce, t)]; maxb = max(maxb, (cnt[t] + 63u) >> 6); }
+  const uint32_t n_waves = gridDim.x * 4u;
+  for (uint32_t g = blockIdx.x * 4u + wave; g < maxb * N_SHARDS; g += n_waves) {
+    const uint32_t shard = g & (N_SHARDS - 1), base = (g >> 3) << 6;
+    uint32_t n = 0;
+#pragma unroll
+    for (int t = 0; t < N_SHARDS; t++) n = (shard == (uint32_t)t) ? cnt[t] : n;
+    if (base >= n) continue;
+    const uint32_t q = shard * f.shard_cap + base + lane;
     bool push_next = false, push_shadow = false;
     F3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     float sh_tmax = 0.f; F3 sh_c = mk3(0, 0, 0); float sh_w = 0.f;
     uint32_t sid = SID_DEAD;
-    if (q < n) {
+    if (base + lane < n) {
       const float4 rd = f.ray_d[cur][q];
       sid = __float_as_uint(rd.w);
-      if (sid != SID_DEAD) {
-        const F3 d = mk3(rd.x, rd.y, rd.z);
-        const int inst = f.hit_inst[q];
-        if (inst < 0) {
-          // src/shader.rmiss:11 + src/shader.rgen:90-94
-          const F3 c = sample_sky(a.sc, mk3(d.x, d.y, -d.z));
-          f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
-        } else {
-          // src/shader.rchit:50-96
-          const float4 h = f.hit_a[q];
-          const InstanceDev* I = a.sc.inst + inst;
-          const uint32_t prim = __float_as_uint(h.w);
-          const uint32_t* ix = a.sc.idx + I->first_index + 3u * prim;
-          const uint32_t ia = ix[0], ib = ix[1], ic = ix[2];
-          const float* vb = a.sc.verts + I->first_float;
-          const float bx = (1.0f - h.y) - h.z, by = h.y, bz = h.z;
-          const float* pa = vb + 6u * ia; const float* pb = vb + 6u * ib; const float* pc = vb + 6u * ic;
-          const F3 pos = fma3(bz, mk3(pc[0], pc[1], pc[2]), fma3(by, mk3(pb[0], pb[1], pb[2]), mul3(mk3(pa[0], pa[1], pa[2]), bx)));
-          const F3 nrm = fma3(bz, mk3(pc[3], pc[4], pc[5]), fma3(by, mk3(pb[3], pb[4], pb[5]), mul3(mk3(pa[3], pa[4], pa[5]), bx)));
-          const F3 P = xform_point(I->o2w, pos);
-          F3 N = normalize3(xform_normal(I->w2o, nrm));
-          const int objectIndex = I->custom_index;
-          const uint32_t type = objectIndex == 0 ? U.center_object_type : U.orbiting_object_type;
-          const bool last = (uint32_t)a.bounce >= U.max_bounce_count;
-          if (type == 0u) {
-            // src/shader.rgen:97-131
-            if (dot3(d, N) >= 0.0f) {
-              f.sample_color[sid] = make_float4(0.08f, 0.24f, 0.08f, 1.0f);
-            } else {
-              no = fma3(0.01f, N, P);
-              const F3 toL = sub3(mk3(U.light_position[0], U.light_position[1], U.light_position[2]), P);
-              const float dist = length3(toL);
-              const F3 L = mul3(toL, 1.0f / dist);
-              const F3 Hh = normalize3(add3(L, neg3(d)));
-              const float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
-              const float dl = fmaxf(0.0f, NdotL), sp = pow100(fmaxf(0.0f, NdotH));
-              const uint32_t i = sid / (uint32_t)(f.rows * f.width);
-              float w = 1.0f;
-              for (uint32_t k = 0; k < i; k++) w = w * 0.9f;
-              const float Iv = U.light_intensity;
-              const F3 diff = mk3((Iv * 0.2f) * dl, (Iv * 1.0f) * dl, (Iv * 0.2f) * dl);
-              const float sv = (Iv * 0.8f) * sp;
-              sh_c = add3(diff, mk3(sv, sv, sv)); sh_w = w;
-              nd = L; sh_tmax = dist;
-              push_shadow = true;
-            }
-          } else if (type == 1u) {
-            // src/shader.rgen:132-138
-            no = fma3(0.01f, N, P);
-            nd = reflect3(d, N);
-            push_next = true;
-          } else if (type == 2u) {
-            // src/shader.rgen:139-165
-            float ndoti = dot3(d, N);
-            const bool outwards = ndoti > 0.0f;
-            if (outwards) { N = neg3(N); ndoti = -ndoti; }
-            const float ratio = outwards ? 1.52f : (1.0f / 1.52f);
-            const float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
-            if (k < 0.0f) { nd = reflect3(d, N); no = fma3(0.01f, N, P); }
-            else {
-              const float c = __builtin_fmaf(ratio, ndoti, __builtin_sqrtf(k));
-              nd = normalize3(fma3(-c, N, mul3(d, ratio)));
-              no = fma3(-0.01f, N, P);
-            }
-            push_next = true;
-          } else {
-            // unknown type: the reference loop re-traces the unchanged ray until the bounce budget ends
-            const float4 ro = f.ray_o[cur][q];
-            no = mk3(ro.x, ro.y, ro.z); nd = d; push_next = true;
-          }
-          if (push_next && last) {
-            // loop of src/shader.rgen:84 ends: tmpColor keeps Iamb*ka
-            push_next = false;
+      const F3 d = mk3(rd.x, rd.y, rd.z);
+      const int inst = f.hit_inst[q];
+      if (inst < 0) {
+        // src/shader.rmiss:11 + src/shader.rgen:90-94
+        const F3 c = sample_sky(a.sc, mk3(d.x, d.y, -d.z));
+        f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
+      } else {
+        // src/shader.rchit:50-96
+        const float4 h = f.hit_a[q];
+        const InstanceDev* I = a.sc.inst + inst;
+        const uint32_t prim = __float_as_uint(h.w);
+        const uint32_t* ix = a.sc.idx + I->first_index + 3u * prim;
+        const uint32_t ia = ix[0], ib = ix[1], ic = ix[2];
+        const float* vb = a.sc.verts + I->first_float;
+        const float bx = (1.0f - h.y) - h.z, by = h.y, bz = h.z;
+        const float* pa = vb + 6u * ia; const float* pb = vb + 6u * ib; const float* pc = vb + 6u * ic;
+        const F3 pos = fma3(bz, mk3(pc[0], pc[1], pc[2]), fma3(by, mk3(pb[0], pb[1], pb[2]), mul3(mk3(pa[0], pa[1], pa[2]), bx)));
+        const F3 nrm = fma3(bz, mk3(pc[3], pc[4], pc[5]), fma3(by, mk3(pb[3], pb[4], pb[5]), mul3(mk3(pa[3], pa[4], pa[5]), bx)));
+        const F3 P = xform_point(I->o2w, pos);
+        F3 N = normalize3(xform_normal(I->w2o, nrm));
+        const int objectIndex = I->custom_index;
+        const uint32_t type = objectIndex == 0 ? U.center_object_type : U.orbiting_object_type;
+        const bool last = (uint32_t)a.bounce >= U.max_bounce_count;
+        if (type == 0u) {
+          // src/shader.rgen:97-131
+          if (dot3(d, N) >= 0.0f) {
             f.sample_color[sid] = make_float4(0.08f, 0.24f, 0.08f, 1.0f);
+          } else {
+            no = fma3(0.01f, N, P);
+            const F3 toL = sub3(mk3(U.light_position[0], U.light_position[1], U.light_position[2]), P);
+            const float dist = length3(toL);
+            const F3 L = mul3(toL, 1.0f / dist);
+            const F3 Hh = normalize3(add3(L, neg3(d)));
+            const float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
+            const float dl = fmaxf(0.0f, NdotL), sp = pow100(fmaxf(0.0f, NdotH));
+            const uint32_t i = sid / (uint32_t)(f.rows * f.width);
+            float w = 1.0f;
+            for (uint32_t k = 0; k < i; k++) w = w * 0.9f;
+            const float Iv = U.light_intensity;
+            const F3 diff = mk3((Iv * 0.2f) * dl, (Iv * 1.0f) * dl, (Iv * 0.2f) * dl);
+            const float sv = (Iv * 0.8f) * sp;
+            sh_c = add3(diff, mk3(sv, sv, sv)); sh_w = w;
+            nd = L; sh_tmax = dist;
+            push_shadow = true;
           }
+        } else if (type == 1u) {
+          // src/shader.rgen:132-138
+          no = fma3(0.01f, N, P);
+          nd = reflect3(d, N);
+          push_next = true;
+        } else if (type == 2u) {
+          // src/shader.rgen:139-165
+          float ndoti = dot3(d, N);
+          const bool outwards = ndoti > 0.0f;
+          if (outwards) { N = neg3(N); ndoti = -ndoti; }
+          const float ratio = outwards ? 1.52f : (1.0f / 1.52f);
+          const float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
+          if (k < 0.0f) { nd = reflect3(d, N); no = fma3(0.01f, N, P); }
+          else {
+            const float c = __builtin_fmaf(ratio, ndoti, __builtin_sqrtf(k));
+            nd = normalize3(fma3(-c, N, mul3(d, ratio)));
+            no = fma3(-0.01f, N, P);
+          }
+          push_next = true;
+        } else {
+          // unknown type: the reference loop re-traces the unchanged ray until the bounce budget ends
+          const float4 ro = f.ray_o[cur][q];
+          no = mk3(ro.x, ro.y, ro.z); nd = d; push_next = true;
+        }
+        if (push_next && last) {
+          // loop of src/shader.rgen:84 ends: tmpColor keeps Iamb*ka
+          push_next = false;
+          f.sample_color[sid] = make_float4(0.08f, 0.24f, 0.08f, 1.0f);
         }
       }
     }
-    // wavefront ballot compaction into the next-bounce queue / the shadow queue
-    const uint32_t slot_n = wave_alloc(push_next, f.counters + CNT_QUEUE0 + a.bounce + 1);
+    // wavefront ballot compaction into the next-bounce queue / the shadow queue of the same shard
+    const uint32_t slot_n = wave_alloc(push_next, f.counters + cnt_tail(a.bounce + 1, (int)shard));
     if (push_next) {
-      f.ray_o[nxt][slot_n] = make_float4(no.x, no.y, no.z, 10000.0f);
-      f.ray_d[nxt][slot_n] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
+      const uint32_t v = shard * f.shard_cap + slot_n;
+      f.ray_o[nxt][v] = make_float4(no.x, no.y, no.z, 10000.0f);
+      f.ray_d[nxt][v] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
     }
-    const uint32_t slot_s = wave_alloc(push_shadow, f.counters + CNT_SHADOW);
+    const uint32_t slot_s = wave_alloc(push_shadow, f.counters + cnt_tail(Q_SHADOW, (int)shard));
     if (push_shadow) {
-      f.sh_o[slot_s] = make_float4(no.x, no.y, no.z, sh_tmax);
-      f.sh_d[slot_s] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
-      f.sh_c[slot_s] = make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w);
+      const uint32_t v = shard * f.shard_cap + slot_s;
+      f.sh_o[v] = make_float4(no.x, no.y, no.z, sh_tmax);
+      f.sh_d[v] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
+      f.sh_c[v] = make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w);
     }
   }
 }
@@ -516,51 +794,56 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
 // launchers
 int trace_threads_per_block() { return 256; }
 
-void launch_raygen(const FrameDev& f, const UniformsDev& u, hipStream_t s) {
+void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s) {
   const uint32_t tiles = (((uint32_t)f.width + 7u) >> 3) * (((uint32_t)f.rows + 7u) >> 3);
   const uint32_t total = tiles * u.samples_per_pixel * 64u;
-  hipLaunchKernelGGL(k_raygen, dim3((total + 255u) / 256u), dim3(256), 0, s, f, u);
+  hipLaunchKernelGGL(k_raygen, dim3((total + 255u) / 256u), dim3(256), 0, s, sc, f, u);
 }
 
-static TraceArgs make_args(const SceneDev& sc) {
+static TraceArgs make_args(const SceneDev& sc, uint32_t* counters, int queue, uint32_t shard_cap, int32_t* ovf) {
   TraceArgs a{};
   a.sc = sc;
   a.tmin = 0.001f;  // src/shader.rgen:87,112
+  a.counters = counters;
+  a.tails = counters + cnt_tail(queue, 0);
+  a.work = counters + cnt_work(queue, 0);
+  a.shard_cap = shard_cap;
+  a.ovf_stack = ovf;
   return a;
 }
 
+template <int MODE, bool ANY>
+static void launch_trace(const TraceArgs& a, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+  const dim3 g(cfg.trace_blocks), b(256);
+  if (cfg.variant == 0) {
+    if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE, ANY, false>), g, b, 0, s, a);
+  } else {
+    if (counting) hipLaunchKernelGGL((k_trace4<MODE, ANY, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace4<MODE, ANY, false>), g, b, 0, s, a);
+  }
+}
+
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
-  TraceArgs a = make_args(sc);
+  TraceArgs a = make_args(sc, f.counters, bounce, f.shard_cap, f.ovf_stack);
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
-  a.n_ptr = f.counters + CNT_QUEUE0 + bounce;
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
-  a.ovf_stack = f.ovf_stack; a.counters = f.counters;
-  if (counting) hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, true>), dim3(cfg.trace_blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false>), dim3(cfg.trace_blocks), dim3(256), 0, s, a);
+  launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
 }
 
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s) {
-  TraceArgs a = make_args(sc);
+  TraceArgs a = make_args(sc, f.counters, Q_SHADOW, f.shard_cap, f.ovf_stack);
   a.ray_o = f.sh_o; a.ray_d = f.sh_d; a.sh_c = f.sh_c;
-  a.n_ptr = f.counters + CNT_SHADOW;
   a.sample_color = f.sample_color;
-  a.ovf_stack = f.ovf_stack; a.counters = f.counters;
-  if (counting) hipLaunchKernelGGL((k_trace<MODE_SHADOW, true, true>), dim3(cfg.trace_blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_trace<MODE_SHADOW, true, false>), dim3(cfg.trace_blocks), dim3(256), 0, s, a);
+  launch_trace<MODE_SHADOW, true>(a, counting, cfg, s);
 }
 
-void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, const uint32_t* n_ptr,
+void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, uint32_t shard_cap,
                       int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s) {
-  TraceArgs a = make_args(sc);
-  a.ray_o = ray_o; a.ray_d = ray_d; a.n_ptr = n_ptr; a.raw_out = out; a.ovf_stack = ovf_stack; a.counters = counters;
-  dim3 g(cfg.trace_blocks), b(256);
-  if (any_hit) {
-    if (counting) hipLaunchKernelGGL((k_trace<MODE_RAW, true, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE_RAW, true, false>), g, b, 0, s, a);
-  } else {
-    if (counting) hipLaunchKernelGGL((k_trace<MODE_RAW, false, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE_RAW, false, false>), g, b, 0, s, a);
-  }
+  TraceArgs a = make_args(sc, counters, 0, shard_cap, ovf_stack);
+  a.ray_o = ray_o; a.ray_d = ray_d; a.raw_out = out;
+  if (any_hit) launch_trace<MODE_RAW, true>(a, counting, cfg, s);
+  else launch_trace<MODE_RAW, false>(a, counting, cfg, s);
 }
 
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s) {

@@ -34,8 +34,9 @@ struct Mesh {
   rt_mesh_range range{};
   bool built = false;
   BuiltBvh bvh;
+  Bvh4 bvh4;
   std::vector<TriPacket> tris;
-  int32_t node_base = 0;   // position of this mesh's nodes / packets in the linked arrays
+  int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays
   uint32_t tri_base = 0;
 };
 
@@ -59,6 +60,9 @@ struct rt_ctx {
   std::vector<Mesh> meshes;
   bool blas_linked = false;
   BvhNode* d_blas_nodes = nullptr;
+  Bvh4Node* d_nodes4 = nullptr;     // BLAS BVH4 nodes followed by the TLAS BVH4 nodes
+  size_t cap_nodes4 = 0, n_blas4 = 0;
+  std::vector<Bvh4Node> h_blas4;
   float4* d_tris = nullptr;
   size_t n_blas_nodes = 0, n_tris = 0;
 
@@ -66,6 +70,7 @@ struct rt_ctx {
   std::vector<rt_instance> h_inst;
   std::vector<InstanceDev> h_inst_dev;
   BuiltBvh tlas;
+  Bvh4 tlas4;
   bool tlas_valid = false;
   InstanceDev* d_inst = nullptr;
   BvhNode* d_tlas_nodes = nullptr;
@@ -151,13 +156,14 @@ Aabb instance_world_box(const float o2w[12], const Aabb& b) {
 
 int link_blas(rt_ctx* c) {
   // concatenate every built mesh into one node array / one packet array with global references
-  size_t nn = 0, nt = 0;
+  size_t nn = 0, nt = 0, nn4 = 0;
   for (auto& m : c->meshes) {
     if (!m.built) continue;
-    m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt;
-    nn += m.bvh.nodes.size(); nt += m.tris.size();
+    m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt; m.node_base4 = (int32_t)nn4;
+    nn += m.bvh.nodes.size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
   }
   std::vector<BvhNode> nodes(nn);
+  std::vector<Bvh4Node> nodes4(nn4);
   std::vector<TriPacket> tris(nt);
   for (auto& m : c->meshes) {
     if (!m.built) continue;
@@ -172,10 +178,22 @@ int link_blas(rt_ctx* c) {
       n.child0 = fix(n.child0); n.child1 = fix(n.child1);
       nodes[m.node_base + i] = n;
     }
+    for (size_t i = 0; i < m.bvh4.nodes.size(); i++) {
+      Bvh4Node n = m.bvh4.nodes[i];
+      for (int k = 0; k < 4; k++) {
+        int32_t ch = n.c[k].ref;
+        if (ch == 0x7FFFFFFF) continue;
+        if (ch >= 0) n.c[k].ref = ch + m.node_base4;
+        else { uint32_t ref = (uint32_t)(~ch); n.c[k].ref = ~(int32_t)((((ref >> 3) + m.tri_base) << 3) | (ref & 7u)); }
+      }
+      nodes4[m.node_base4 + i] = n;
+    }
     if (!m.tris.empty()) memcpy(&tris[m.tri_base], m.tris.data(), m.tris.size() * sizeof(TriPacket));
   }
   if (c->d_blas_nodes) { HIP_TRY(c, hipFree(c->d_blas_nodes)); c->d_blas_nodes = nullptr; }
   if (c->d_tris) { HIP_TRY(c, hipFree(c->d_tris)); c->d_tris = nullptr; }
+  if (c->d_nodes4) { HIP_TRY(c, hipFree(c->d_nodes4)); c->d_nodes4 = nullptr; c->cap_nodes4 = 0; }
+  c->h_blas4.swap(nodes4); c->n_blas4 = nn4;
   HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, std::max<size_t>(1, nn) * sizeof(BvhNode)));
   HIP_TRY(c, hipMalloc((void**)&c->d_tris, std::max<size_t>(1, nt) * sizeof(TriPacket)));
   if (nn) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, nodes.data(), nn * sizeof(BvhNode), hipMemcpyHostToDevice));
@@ -200,6 +218,19 @@ int upload_instances(rt_ctx* c) {
   // stream-ordered so a per-frame update never stalls the host on a fence (the reference blocks on
   // vkWaitForFences every frame, src/main.cpp:772-778)
   HIP_TRY(c, hipMemcpyAsync(c->d_inst, c->h_inst_dev.data(), n * sizeof(InstanceDev), hipMemcpyHostToDevice, c->stream));
+  // quad traversal: one node array (BLAS nodes, then TLAS nodes with their interior links rebased)
+  const size_t need4 = c->n_blas4 + c->tlas4.nodes.size();
+  if (need4 > c->cap_nodes4) {
+    if (c->d_nodes4) HIP_TRY(c, hipFree(c->d_nodes4));
+    c->cap_nodes4 = need4 + 64;
+    HIP_TRY(c, hipMalloc((void**)&c->d_nodes4, c->cap_nodes4 * sizeof(Bvh4Node)));
+    if (c->n_blas4) HIP_TRY(c, hipMemcpy(c->d_nodes4, c->h_blas4.data(), c->n_blas4 * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+  }
+  std::vector<Bvh4Node> t4 = c->tlas4.nodes;
+  for (auto& nd : t4)
+    for (int k = 0; k < 4; k++)
+      if (nd.c[k].ref >= 0 && nd.c[k].ref != 0x7FFFFFFF) nd.c[k].ref += (int32_t)c->n_blas4;
+  HIP_TRY(c, hipMemcpyAsync(c->d_nodes4 + c->n_blas4, t4.data(), t4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(c->d_tlas_nodes, c->tlas.nodes.data(), c->tlas.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rewritten by the next call
   return RT_OK;
@@ -207,6 +238,7 @@ int upload_instances(rt_ctx* c) {
 
 SceneDev scene_dev(const rt_ctx* c) {
   SceneDev s{};
+  s.nodes4 = c->d_nodes4; s.tlas_root4 = (int)c->n_blas4;
   s.blas_nodes = c->d_blas_nodes; s.tris = c->d_tris; s.tlas_nodes = c->d_tlas_nodes; s.inst = c->d_inst;
   s.verts = c->d_verts; s.idx = c->d_idx; s.sky = c->d_sky; s.n_inst = (int)c->h_inst_dev.size();
   s.sky_w = c->sky_w; s.sky_h = c->sky_h;
@@ -262,12 +294,17 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (u.samples_per_pixel == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "samplesPerPixel must be >= 1");
   if (u.max_bounce_count + 2 > (uint32_t)CNT_MAX_BOUNCES) return fail(c, RT_ERR_INVALID_ARGUMENT, "maxBounceCount too large (max 69)");
   const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
-  const size_t capacity = tiles * u.samples_per_pixel * 64;
-  if (capacity >= 0xFFFFFF00ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for 32-bit sample ids");
-  int r = ensure_frame(c, std::max<size_t>(capacity, 64)); if (r) return r;
+  const size_t samples = tiles * u.samples_per_pixel * 64;   // k_raygen threads
+  if (samples >= 0xF0000000ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for 32-bit sample ids");
+  // k_raygen block b appends to shard b % 8, so a shard never receives more than this many rays; paths
+  // stay in their shard, so the bound holds for every later queue as well
+  const size_t raygen_blocks = (samples + 255) / 256;
+  const size_t shard_cap = std::max<size_t>(256, ((raygen_blocks + N_SHARDS - 1) / N_SHARDS) * 256);
+  const size_t capacity = shard_cap * N_SHARDS;
+  int r = ensure_frame(c, capacity); if (r) return r;
   FrameDev f = c->frame;
   f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out;
-  f.capacity = (uint32_t)capacity; f.width = W; f.height = H; f.rows = rows;
+  f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   const SceneDev sc = scene_dev(c);
   c->ev_used = 0; c->spans.clear();
@@ -278,15 +315,17 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   {
     Span frame_span(c, CAT_FRAME, s);
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s));
-    { Span sp(c, CAT_RAYGEN, s); launch_raygen(f, u, s); }
+    { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
     for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
       { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
       { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
-        uint32_t live = 0;
-        HIP_TRY(c, hipMemcpyAsync(&live, c->d_counters + CNT_QUEUE0 + b + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+        uint32_t tails[N_SHARDS * CNT_STRIDE];
+        HIP_TRY(c, hipMemcpyAsync(tails, c->d_counters + cnt_tail((int)b + 1, 0), sizeof(tails), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
+        uint32_t live = 0;
+        for (int t = 0; t < N_SHARDS; t++) live += tails[t * CNT_STRIDE];
         if (live == 0) break;
       }
     }
@@ -300,18 +339,23 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
 int collect_stats(rt_ctx* c) {
   if (!c->frame_pending) return RT_OK;
   HIP_TRY(c, hipStreamSynchronize(c->frame_stream));
-  uint32_t cnt[CNT_WORDS];
-  HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
+  std::vector<uint32_t> cnt(CNT_WORDS);
+  HIP_TRY(c, hipMemcpy(cnt.data(), c->d_counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  auto queue_size = [&](int qi) { uint64_t n = 0; for (int t = 0; t < N_SHARDS; t++) n += cnt[cnt_tail(qi, t)]; return n; };
   rt_stats st{};
   st.rays_primary = c->last_primary;
-  for (uint32_t b = 1; b <= c->last_max_bounce; b++) st.rays_secondary += cnt[CNT_QUEUE0 + b];
-  st.rays_shadow = cnt[CNT_SHADOW];
-  st.closest_rays = st.rays_primary + st.rays_secondary;
+  for (uint32_t b = 1; b <= c->last_max_bounce; b++) st.rays_secondary += queue_size((int)b);
+  st.rays_shadow = queue_size(Q_SHADOW);
+  // rays that went through the closest-hit traversal kernel: primary rays that survived the TLAS-root
+  // test fused into k_raygen (queue 0) plus every secondary ray
+  st.closest_rays = queue_size(0) + st.rays_secondary;
   memcpy(&st.node_visits, &cnt[CNT_NODE_VISITS], 8);
   memcpy(&st.tri_tests, &cnt[CNT_TRI_TESTS], 8);
   memcpy(&st.node_visits_shadow, &cnt[CNT_NODE_VISITS_SH], 8);
   memcpy(&st.tri_tests_shadow, &cnt[CNT_TRI_TESTS_SH], 8);
-  st.bvh_node_bytes = sizeof(BvhNode); st.bvh_tri_bytes = sizeof(TriPacket);
+  memcpy(&st.diag[0], &cnt[CNT_DIAG], 24);
+  memcpy(&st.diag[3], &cnt[CNT_DIAG_SH], 24);
+  st.bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNode); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
@@ -358,6 +402,8 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   // persistent grids: LDS stacks (24 KB per 256-thread block) admit 6 blocks per CU
   c->cfg.trace_blocks = c->n_cu * 6;
   c->cfg.shade_blocks = c->n_cu * 8;
+  c->cfg.variant = 1;
+  if (const char* env = getenv("RT_TRACE_VARIANT")) c->cfg.variant = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   *out_ctx = c;
   return RT_OK;
@@ -368,7 +414,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_tlas_nodes, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
+  void* ptrs[] = {c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_tlas_nodes, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -413,6 +459,7 @@ int rt_build_blas(rt_ctx* c, int mesh) {
   if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
   Mesh& m = c->meshes[mesh];
   build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
+  collapse_bvh4(m.bvh, true, false, m.bvh4);
   m.built = true;
   c->blas_linked = false; c->tlas_valid = false;
   return RT_OK;
@@ -438,15 +485,22 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     memcpy(d.o2w, inst[i].transform, sizeof(d.o2w));
     invert_affine(d.o2w, d.w2o);
     d.blas_root = m.node_base;
+    d.blas_root4 = m.node_base4;
     d.mask = inst[i].custom_index_and_mask >> 24;
     d.custom_index = (int32_t)(inst[i].custom_index_and_mask & 0xFFFFFFu);
     d.first_float = (uint32_t)m.range.first_float;
     d.first_index = (uint32_t)m.range.first_index;
-    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    d.pad[0] = d.pad[1] = 0;
     boxes[i] = instance_world_box(d.o2w, m.bvh.bounds);
   }
-  if (update) refit_bvh(boxes.data(), c->tlas);
-  else build_bvh(boxes.data(), (uint32_t)n, 1, 20, c->tlas);
+  if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
+  else { build_bvh(boxes.data(), (uint32_t)n, 1, 20, c->tlas); collapse_bvh4(c->tlas, false, true, c->tlas4); }
+  // the quad traversal keeps its whole stack in LDS: bottom sentinel + TLAS + marker + deepest BLAS
+  int blas_need = 0;
+  for (int i = 0; i < n; i++) blas_need = std::max(blas_need, c->meshes[inst[i].mesh].bvh4.stack_need);
+  if (1 + c->tlas4.stack_need + 1 + blas_need > STACK4_LDS)
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
+                    " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
   c->tlas_valid = true;
   return upload_instances(c);
 }
@@ -479,6 +533,19 @@ int rt_shard_rows(int height, int band_rows, int shard, int n_shards) {
   int rows = 0;
   for (int b = shard; b < n_bands; b += n_shards) rows += std::min(band_rows, height - b * band_rows);
   return rows;
+}
+
+int rt_set_param(rt_ctx* c, const char* name, int value) {
+  if (!c || !name) return RT_ERR_INVALID_ARGUMENT;
+  std::string k(name);
+  if (k == "trace_variant") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0 or 1"); c->cfg.variant = value; return RT_OK; }
+  if (k == "trace_blocks_per_cu") {
+    if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
+    if (c->d_ovf && value * c->n_cu > c->cfg.trace_blocks) { hipFree(c->d_ovf); c->d_ovf = nullptr; }
+    c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
+  }
+  if (k == "shade_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "shade_blocks_per_cu must be 1..16"); c->cfg.shade_blocks = c->n_cu * value; return RT_OK; }
+  return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown parameter " + k);
 }
 
 int rt_set_timing(rt_ctx* c, int enabled) { if (!c) return RT_ERR_INVALID_ARGUMENT; c->timing = enabled != 0; return RT_OK; }
@@ -558,23 +625,23 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
   HIP_TRY(c, hipMemcpy(d_d, hd.data(), n * sizeof(float4), hipMemcpyHostToDevice));
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), c->stream));
   uint32_t n32 = (uint32_t)n;
-  HIP_TRY(c, hipMemcpyAsync(c->d_counters + CNT_QUEUE0, &n32, sizeof(n32), hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_counters + cnt_tail(0, 0), &n32, sizeof(n32), hipMemcpyHostToDevice, c->stream));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0, c->stream);
-  launch_trace_raw(scene_dev(c), d_o, d_d, d_h, c->d_counters + CNT_QUEUE0, c->d_ovf, c->d_counters, any_hit != 0, counting != 0, c->cfg, c->stream);
+  launch_trace_raw(scene_dev(c), d_o, d_d, d_h, n32, c->d_ovf, c->d_counters, any_hit != 0, counting != 0, c->cfg, c->stream);
   hipEventRecord(e1, c->stream);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpy(out, d_h, n * sizeof(HitRec), hipMemcpyDeviceToHost));
   if (stats) {
-    uint32_t cnt[CNT_WORDS];
+    uint32_t cnt[CNT_TAILS];
     HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));
     memcpy(&stats->node_visits, &cnt[any_hit ? CNT_NODE_VISITS_SH : CNT_NODE_VISITS], 8);
     memcpy(&stats->tri_tests, &cnt[any_hit ? CNT_TRI_TESTS_SH : CNT_TRI_TESTS], 8);
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     if (any_hit) stats->ms_trace_shadow = ms; else stats->ms_trace_closest = ms;
     stats->closest_rays = any_hit ? 0 : n; stats->rays_shadow = any_hit ? n : 0;
-    stats->bvh_node_bytes = sizeof(BvhNode); stats->bvh_tri_bytes = sizeof(TriPacket);
+    stats->bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNode); stats->bvh_tri_bytes = sizeof(TriPacket);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
   hipFree(d_o); hipFree(d_d); hipFree(d_h);

@@ -22,6 +22,22 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// BVH4 node for the quad-cooperative traversal (4 lanes per ray): 128 B = one cache line, child k at
+// byte 32k so that the 4 lanes of a quad read 4 consecutive 32-byte records (2 x dwordx4 each).
+//   (lo.x, lo.y, lo.z, hi.x) (hi.y, hi.z, ref, 0);  ref as in BvhNode::child*; a missing child is the
+//   far-point box with ref 0x7FFFFFFF.
+struct alignas(16) Bvh4Child {
+  float lo[3];
+  float hix;
+  float hiy, hiz;
+  int32_t ref;
+  uint32_t pad;
+};
+struct alignas(128) Bvh4Node {
+  Bvh4Child c[4];
+};
+static_assert(sizeof(Bvh4Node) == 128, "Bvh4Node must be 128 bytes");
+
 // Triangle packet in leaf order, 48 B = 3 x dwordx4.  e1 = v1 - v0 and e2 = v2 - v0 are rounded
 // once in binary32 exactly as the oracle computes them at test time.
 struct alignas(16) TriPacket {
@@ -42,7 +58,8 @@ struct alignas(16) InstanceDev {
   int32_t custom_index; // gl_InstanceCustomIndexEXT
   uint32_t first_float; // vertexOffset of src/shader.rchit:55 (floats)
   uint32_t first_index; // 3*primitive offset of src/shader.rchit:54 (uint32s)
-  uint32_t pad[3];
+  int32_t blas_root4;   // root of the mesh in blas_nodes4 (BVH4)
+  uint32_t pad[2];
 };
 static_assert(sizeof(InstanceDev) == 128, "InstanceDev must be 128 bytes");
 
@@ -58,19 +75,37 @@ static_assert(sizeof(UniformsDev) == 104, "UniformsDev must be 104 bytes");
 
 struct HitRec { float t, u, v; int32_t prim, inst; };  // == rt_hit
 
-// counters[] layout (uint32 unless noted), zeroed at frame start
+// ---- queues and counters ---------------------------------------------------------------------
+// Every ray queue is split into N_SHARDS regions of `shard_cap` entries (entry v = shard*shard_cap +
+// slot).  A path never leaves the shard its primary ray was generated in, producers append with one
+// wave-aggregated atomic on the shard's own tail, consumers pull 64-ray chunks from the shard's own
+// cursor and steal from the other shards when theirs runs dry.  Blocks use shard blockIdx % 8, which
+// under round-robin dispatch is their XCD: the rays a shard's producers write are read back through
+// the same XCD's L2, and no single atomic word sees more than 1/8 of the traffic (one returning
+// atomic word saturates near 88 operations/us on MI355X).  Placement is a speed hint, never assumed.
+constexpr int N_SHARDS = 8;
+constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: one 128-byte line each
+constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounceCount <= 69)
+constexpr int Q_SHADOW = CNT_MAX_BOUNCES;      // queue id of the shadow-ray queue
+constexpr int N_QUEUES = CNT_MAX_BOUNCES + 1;
 enum : int {
-  CNT_SHADOW = 0,        // shadow-queue tail = number of shadow rays
-  CNT_QUEUE0 = 1,        // CNT_QUEUE0 + b = rays in the queue of bounce b (b = 0: primary, incl. dead pads)
-  CNT_MAX_BOUNCES = 72,
-  CNT_NODE_VISITS = 80,  // uint64 at [80,81]   closest-hit kernel (counting builds only)
-  CNT_TRI_TESTS = 82,    // uint64 at [82,83]
-  CNT_NODE_VISITS_SH = 84,  // uint64: any-hit (shadow) kernel
-  CNT_TRI_TESTS_SH = 86,
-  CNT_WORDS = 96
+  CNT_NODE_VISITS = 0,     // uint64: closest-hit kernel (counting builds only)
+  CNT_TRI_TESTS = 2,       // uint64
+  CNT_NODE_VISITS_SH = 4,  // uint64: any-hit (shadow) kernel
+  CNT_TRI_TESTS_SH = 6,    // uint64
+  CNT_DIAG = 8,            // 3 x uint64 (diagnostic counting build): loop trips, busy quad-trips, wave cycles
+  CNT_DIAG_SH = 16,
+  CNT_TAILS = 32
 };
+constexpr int CNT_WORKS = CNT_TAILS + N_QUEUES * N_SHARDS * CNT_STRIDE;
+constexpr int CNT_WORDS = CNT_WORKS + N_QUEUES * N_SHARDS * CNT_STRIDE;
+// tail (= number of entries) of shard `shard` of queue `queue`; chunk cursor of the launch that consumes it
+constexpr inline int cnt_tail(int queue, int shard) { return CNT_TAILS + (queue * N_SHARDS + shard) * CNT_STRIDE; }
+constexpr inline int cnt_work(int queue, int shard) { return CNT_WORKS + (queue * N_SHARDS + shard) * CNT_STRIDE; }
 
 constexpr uint32_t SID_DEAD = 0xFFFFFFFFu;   // padding lane of the primary queue
+constexpr int STACK4_LDS = 64;               // quad kernel: stack entries per RAY, all in LDS; the builder
+                                             // verifies the worst case of every tree against it
 constexpr int STACK_LDS = 24;                // per-lane traversal stack entries kept in LDS
 constexpr int STACK_OVF = 40;                // spill entries per lane in HBM (never touched by sane trees)
 constexpr int BLAS_MAX_DEPTH = 40;           // builder-enforced; TLAS <= 20; + 1 return marker <= 64

@@ -11,6 +11,8 @@ struct SceneDev {
   const BvhNode* blas_nodes;
   const float4* tris;          // 3 float4 per TriPacket
   const BvhNode* tlas_nodes;
+  const Bvh4Node* nodes4;      // quad traversal (variant 1): BLAS BVH4 nodes, then the TLAS BVH4 nodes
+  int tlas_root4;              // index of the TLAS root in nodes4
   const InstanceDev* inst;
   const float* verts;          // binding 3 (src/main.cpp:1305-1335)
   const uint32_t* idx;         // binding 2
@@ -31,7 +33,7 @@ struct FrameDev {
   uint32_t* counters;          // rt::CNT_* layout
   int32_t* ovf_stack;          // STACK_OVF ints per persistent thread
   float4* out;                 // compact shard image (rows x W RGBA32F)
-  uint32_t capacity;           // queue capacity in rays
+  uint32_t shard_cap;          // entries per queue shard (queues hold N_SHARDS * shard_cap rays)
   int width, height;           // full frame
   int rows;                    // rows rendered by this shard (compact)
   int band_rows, shard, n_shards;
@@ -40,15 +42,17 @@ struct FrameDev {
 struct LaunchCfg {
   int trace_blocks;            // persistent grid of the traversal kernels (256 threads each)
   int shade_blocks;
+  int variant;                 // 0: BVH2, one lane per ray; 1: BVH4, four lanes per ray (default)
 };
 
-void launch_raygen(const FrameDev& f, const UniformsDev& u, hipStream_t s);
+void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
 // record-level traceRayEXT on raw rays: o = (o.xyz, tmin), d = (d.xyz, tmax); writes HitRec[n]
-void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, const uint32_t* n_ptr,
+// counters must hold the ray count in cnt_tail(0, 0) and zeros elsewhere; rays form shard 0 of capacity shard_cap
+void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, uint32_t shard_cap,
                       int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s);
 
 int trace_threads_per_block();
