@@ -1,0 +1,140 @@
+// rt_headless.cpp — headless counterpart of the reference's main() (src/main.cpp:796-3062) around the
+// ray-tracing stage: config.h defaults -> OBJ ingest -> geometry/BLAS/TLAS -> uniforms -> skybox ->
+// per-frame { animate, TLAS refit, camera -> uniforms, trace } -> image files + Mrays/s.
+// Everything Vulkan/GLFW-specific (window, swapchain, descriptors, SBT, present) has no counterpart:
+// the stage is reached through the C ABI (include/rt_api.h) instead of vkCmdTraceRaysKHR.
+//
+//   rt_headless [--width W] [--height H] [--frames N] [--dt SECONDS] [--bounce B] [--spp S]
+//               [--center OBJ] [--orbiting OBJ] [--center-type T] [--orbiting-type T]
+//               [--skybox DIR] [--out PREFIX] [--device D]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <string>
+#include <vector>
+
+#include "camera.h"
+#include "config.h"
+#include "jpeg_decode.h"
+#include "rt_host.hpp"
+
+static void writePFM(const std::string& path, const std::vector<float>& rgba, int W, int H) {
+  std::ofstream f(path, std::ios::binary);
+  f << "PF\n" << W << " " << H << "\n-1.0\n";
+  std::vector<float> row((size_t)W * 3);
+  for (int y = H - 1; y >= 0; y--) {  // PFM stores the bottom row first
+    for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = rgba[((size_t)y * W + x) * 4 + c];
+    f.write((const char*)row.data(), (std::streamsize)(row.size() * sizeof(float)));
+  }
+}
+// 8-bit view: what the reference's UNORM swapchain-format storage image holds (src/main.cpp:1899): clamp + round
+static void writePPM(const std::string& path, const std::vector<float>& rgba, int W, int H) {
+  std::ofstream f(path, std::ios::binary);
+  f << "P6\n" << W << " " << H << "\n255\n";
+  std::vector<unsigned char> row((size_t)W * 3);
+  for (int y = 0; y < H; y++) {
+    for (int x = 0; x < W; x++)
+      for (int c = 0; c < 3; c++) {
+        float v = rgba[((size_t)y * W + x) * 4 + c];
+        v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+        row[(size_t)x * 3 + c] = (unsigned char)std::lround(v * 255.0f);
+      }
+    f.write((const char*)row.data(), (std::streamsize)row.size());
+  }
+}
+
+int main(int argc, char** argv) {
+  int W = 800, H = 600;  // the reference's window size (src/main.cpp:805)
+  int frames = 3, device = 0;
+  float dt = 1.0f / 60.0f;
+  std::string center = CENTER_MESH_OBJ_PATH, orbiting = ORBITING_MESH_OBJ_PATH, skyDir = SKYBOX_TEXTURE_DIR, out = "frame";
+  rt_uniforms uniformStructure = rthost::defaultUniforms();
+  for (int i = 1; i < argc; i++) {
+    std::string a = argv[i];
+    auto next = [&]() -> const char* { if (i + 1 >= argc) { fprintf(stderr, "missing value for %s\n", a.c_str()); exit(2); } return argv[++i]; };
+    if (a == "--width") W = atoi(next());
+    else if (a == "--height") H = atoi(next());
+    else if (a == "--frames") frames = atoi(next());
+    else if (a == "--dt") dt = (float)atof(next());
+    else if (a == "--bounce") uniformStructure.max_bounce_count = (uint32_t)atoi(next());
+    else if (a == "--spp") uniformStructure.samples_per_pixel = (uint32_t)atoi(next());
+    else if (a == "--center") center = next();
+    else if (a == "--orbiting") orbiting = next();
+    else if (a == "--center-type") uniformStructure.center_object_type = (uint32_t)atoi(next());
+    else if (a == "--orbiting-type") uniformStructure.orbiting_object_type = (uint32_t)atoi(next());
+    else if (a == "--skybox") skyDir = next();
+    else if (a == "--out") out = next();
+    else if (a == "--device") device = atoi(next());
+    else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
+  }
+  try {
+    // resources/armadillo.obj is absent from the reference snapshot: fall back to the labelled stand-in
+    std::string meshLabel = orbiting;
+    if (!std::ifstream(orbiting).good() && orbiting.find("armadillo.obj") != std::string::npos) {
+      orbiting = "resources/generated/armadillo_standin_f132.obj";
+      if (!std::ifstream(orbiting).good()) { if (system("mkdir -p resources/generated") != 0) {} rthost::writeArmadilloStandin(orbiting, 132); }
+      meshLabel = "armadillo STAND-IN (geodesic f=132)";
+    }
+    // OBJ Model, Vertex Buffer, Index Buffer (src/main.cpp:1606-1729)
+    rthost::SceneGeometry geometry = rthost::loadScene({center, orbiting});
+    uniformStructure.orbiting_object_primitive_offset = geometry.orbitingObjectPrimitiveOffset();  // :1872
+    uniformStructure.orbiting_object_vertex_offset = geometry.orbitingObjectVertexOffset();        // :1873
+
+    rthost::Renderer renderer(device);
+    renderer.uploadGeometry(geometry);  // + Bottom Level Acceleration Structures (src/main.cpp:1734-1799)
+
+    // Top Level Acceleration Structure (src/main.cpp:1805-1835)
+    rthost::SceneAnimation animation;
+    auto makeInstances = [&]() {
+      std::vector<rt_instance> inst(2);
+      float transformMatrix[12];
+      for (uint32_t i = 0; i < 2; i++) {
+        rthost::glmToVulkan(animation.glmMatrices[i], transformMatrix);
+        inst[i] = rthost::createInstance(transformMatrix, i, i);
+      }
+      return inst;
+    };
+    renderer.setInstances(makeInstances(), false);
+
+    // Skybox (src/main.cpp:2064-2080): right, left, top, bottom, front, back
+    const char* faces[6] = {"right", "left", "top", "bottom", "front", "back"};
+    std::vector<std::vector<uint8_t>> sky(6);
+    int sw = 0, sh = 0;
+    for (int f = 0; f < 6; f++) {
+      rtjpeg::Image img; std::string err;
+      if (!rtjpeg::decode_file((skyDir + "/" + faces[f] + ".jpg").c_str(), img, err)) throw std::runtime_error("skybox: " + err);
+      sky[f].swap(img.rgba); sw = img.w; sh = img.h;
+    }
+    renderer.setSkybox(sky, sw, sh);
+    renderer.setUniforms(uniformStructure);
+    renderer.setTiming(true);
+
+    Camera camera;  // (0,0,20) looking down -z (src/camera.cpp:8-14)
+    std::vector<float> image;
+    float timeParam = 0.f;
+    for (int frame = 0; frame < frames; frame++) {
+      // main loop body (src/main.cpp:2795-2949) with a fixed time step instead of the wall clock
+      timeParam += dt * 0.1f;
+      animation.animate(timeParam);
+      renderer.setInstances(makeInstances(), true);  // createTLAS(update = true), src/main.cpp:2853-2861
+      renderer.setUniforms(uniformStructure);        // copyData(uniform), src/main.cpp:2901-2903
+      auto t0 = std::chrono::steady_clock::now();
+      rt_stats st = renderer.trace(W, H, image);
+      double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      uint64_t rays = st.rays_primary + st.rays_secondary + st.rays_shadow;
+      printf("frame %d: %dx%d  rays %llu (primary %llu secondary %llu shadow %llu)  gpu %.3f ms  %.1f Mrays/s  (host round trip %.2f ms)  mesh: %s\n", frame, W, H,
+             (unsigned long long)rays, (unsigned long long)st.rays_primary, (unsigned long long)st.rays_secondary, (unsigned long long)st.rays_shadow,
+             st.ms_frame, rays / (st.ms_frame * 1e3), ms, meshLabel.c_str());
+    }
+    writePFM(out + ".pfm", image, W, H);
+    writePPM(out + ".ppm", image, W, H);
+    printf("wrote %s.pfm (float32) and %s.ppm (8-bit clamped view)\n", out.c_str(), out.c_str());
+  } catch (const std::exception& e) {
+    fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  return 0;
+}
