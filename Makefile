@@ -5,7 +5,9 @@ PKG      := vulkan_raytracing_amd
 CSRC     := $(PKG)/csrc
 # -ffp-contract=off: the kernels' arithmetic is the canonical sequence of DESIGN.md; only explicit
 # __builtin_fmaf fuses.  Division and sqrt stay IEEE-correct (hipcc default).
-HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Iinclude
+# -fno-slp-vectorize: hipcc otherwise packs adjacent f32 ops into v_pk_*_f32, which issue slower than the
+# scalar forms on gfx950 (MI355X_MICROARCH.md 'price of one filler'; measured on the traversal kernels).
+HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vectorize -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-unused-result -Iinclude
 
 all: $(PKG)/librt_mi355x.so oracle
 
@@ -31,3 +33,7 @@ all: $(PKG)/librt_host.so
 # headless C++ host (counterpart of the reference's main()); links the product library only
 rt_headless: host/rt_headless.cpp host/camera.cpp host/standin.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so include/rt_host.hpp
 	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ host/rt_headless.cpp host/camera.cpp host/standin.cpp host/jpeg_decode.cpp -L$(PKG) -lrt_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
+
+# kernel experiments: make exp EXP_NAME=<suffix> EXP_FLAGS="-DRT_EXP_..."  -> librt_mi355x_<suffix>.so (load with RT_LIB_VARIANT)
+exp:
+	$(HIPCC) $(HIPFLAGS) $(EXP_FLAGS) -shared -o $(PKG)/librt_mi355x_$(EXP_NAME).so $(CSRC)/kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp

@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
-    ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 1 = BVH4 quad (default), 0 = BVH2 one lane per ray")
+    ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     args = ap.parse_args()
 
@@ -196,7 +196,7 @@ def main():
         achieved = alg_bytes / t_kernel_s / 1e9 if t_kernel_s > 0 else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": None,
-                              "kernel": "closest-hit traversal (k_trace4<closest>: two-level BVH4, 4 lanes per ray; k_trace<closest> when --variant 0) + Moller-Trumbore",
+                              "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore",
                               "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
                               "algorithmic_bytes_per_launch": alg_bytes / launches,
                               "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,

@@ -148,8 +148,8 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
 /* Enable per-kernel hipEvent timing (adds event records to the stream; default off). */
 int rt_set_timing(rt_ctx* ctx, int enabled);
 
-/* Tunables (no reference counterpart): "trace_variant" 1 = BVH4 / four lanes per ray (default), 0 = BVH2 /
- * one lane per ray; "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16.  Results do not depend on them. */
+/* Tunables (no reference counterpart): "trace_variant" 0 = quantized BVH2 / one lane per ray (default), 1 = BVH4 /
+ * four lanes per ray; "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16.  Results do not depend on them. */
 int rt_set_param(rt_ctx* ctx, const char* name, int value);
 
 /* Record-level entry for traceRayEXT alone (rows a10/a14): n rays of 8 floats (o.xyz, tmin, d.xyz, tmax)

@@ -227,7 +227,7 @@ def test_trace_variants_are_result_identical(ctx):
             img, st = ctx.trace(256, 144)
             out[v] = (g, ga["inst"] >= 0, img, (st.rays_primary, st.rays_secondary, st.rays_shadow))
     finally:
-        ctx.set_param("trace_variant", 1)
+        ctx.set_param("trace_variant", 0)
     assert np.array_equal(out[0][0], out[1][0])
     assert np.array_equal(out[0][1], out[1][1])
     assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]

@@ -66,7 +66,7 @@ def main():
     # coalesced stream; WRITE_SIZE is exact) — both bounds are reported.
     pm = res.get("pmc", {})
     for k in pm:
-        if "k_trace<0" in k and "FETCH_SIZE" in pm[k]:
+        if ("k_trace<0, false, false" in k or "k_trace4<0, false, false" in k) and "FETCH_SIZE" in pm[k]:
             fetch_kib = pm[k]["FETCH_SIZE"]
             write_kib = pm[k].get("WRITE_SIZE", 0.0)
             lo = (fetch_kib + write_kib) * 1024.0

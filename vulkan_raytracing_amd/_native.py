@@ -34,6 +34,10 @@ def load_rt():
         import torch  # noqa: F401
     except ImportError:
         pass
+    # RT_LIB_VARIANT=<suffix> loads librt_mi355x_<suffix>.so (kernel experiments built next to the product)
+    suffix = os.environ.get("RT_LIB_VARIANT")
+    if suffix:
+        return ctypes.CDLL(os.path.join(PKG_DIR, "librt_mi355x_%s.so" % suffix))
     return _load("librt_mi355x.so", "vulkan_raytracing_amd/librt_mi355x.so")
 
 

@@ -302,6 +302,47 @@ void refit_bvh4(const BuiltBvh& b2, Bvh4& b4) {
     }
 }
 
+void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]) {
+  // bounds over every child box actually stored (refits can move them)
+  double lo[3] = {3e38, 3e38, 3e38}, hi[3] = {-3e38, -3e38, -3e38};
+  auto valid = [](const float* bx) { return bx[0] < 1e37f; };
+  for (const BvhNode& n : bvh.nodes) {
+    const float c0[6] = {n.a[0], n.a[1], n.a[2], n.a[3], n.c[0], n.c[1]}, c1[6] = {n.b[0], n.b[1], n.b[2], n.b[3], n.c[2], n.c[3]};
+    for (const float* c : {c0, c1}) {
+      if (!valid(c)) continue;
+      for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)c[2 * k]); hi[k] = std::max(hi[k], (double)c[2 * k + 1]); }
+    }
+  }
+  double scale[3], base[3];
+  for (int k = 0; k < 3; k++) {
+    if (lo[k] > hi[k]) { lo[k] = hi[k] = 0.0; }
+    double ext = hi[k] - lo[k];
+    scale[k] = ext > 0 ? ext * (1.0 + 1e-6) / 65530.0 : 1e-30;
+    base[k] = lo[k] - 2.0 * scale[k];           // quanta 0,1 stay below every stored plane
+    q_lo[k] = (float)base[k]; q_scale[k] = (float)scale[k];
+    // the kernel uses the float values: re-derive the doubles from them so that rounding of base/scale
+    // cannot make a box non-conservative
+    base[k] = q_lo[k]; scale[k] = q_scale[k];
+  }
+  auto qdn = [&](double x, int k) { double q = std::floor((x - base[k]) / scale[k]) - 1.0; return (uint32_t)std::min(65535.0, std::max(0.0, q)); };
+  auto qup = [&](double x, int k) { double q = std::ceil((x - base[k]) / scale[k]) + 1.0; return (uint32_t)std::min(65535.0, std::max(0.0, q)); };
+  out.resize(bvh.nodes.size());
+  for (size_t i = 0; i < bvh.nodes.size(); i++) {
+    const BvhNode& n = bvh.nodes[i];
+    float c0[6] = {n.a[0], n.a[1], n.a[2], n.a[3], n.c[0], n.c[1]}, c1[6] = {n.b[0], n.b[1], n.b[2], n.b[3], n.c[2], n.c[3]};
+    int32_t r0 = n.child0, r1 = n.child1;
+    if (!valid(c1)) { memcpy(c1, c0, sizeof(c0)); r1 = r0; }
+    if (!valid(c0)) { memcpy(c0, c1, sizeof(c1)); r0 = r1; }
+    BvhNodeQ q{};
+    for (int k = 0; k < 3; k++) {
+      q.w[k] = qdn(c0[2 * k], k) | (qup(c0[2 * k + 1], k) << 16);
+      q.w[3 + k] = qdn(c1[2 * k], k) | (qup(c1[2 * k + 1], k) << 16);
+    }
+    q.child0 = r0; q.child1 = r1;
+    out[i] = q;
+  }
+}
+
 void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris) {
   std::vector<Aabb> boxes(n_prims);
   for (uint32_t p = 0; p < n_prims; p++) {

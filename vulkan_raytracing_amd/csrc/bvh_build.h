@@ -51,6 +51,10 @@ void collapse_bvh4(const BuiltBvh& b2, bool area_driven, bool direct_ids, Bvh4& 
 // rewrite the child boxes of b4 from b2.topo (after refit_bvh)
 void refit_bvh4(const BuiltBvh& b2, Bvh4& b4);
 
+// 32-byte quantized form of bvh.nodes (rt_device.h BvhNodeQ).  q_lo/q_scale receive the dequantisation
+// of the tree's bounds.  A missing child (synthetic root of a one-leaf tree) becomes a copy of its sibling.
+void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]);
+
 // BLAS helper: boxes + 48-byte packets for an indexed triangle mesh in the reference's layout
 // (positions at verts6[6*i .. 6*i+2], object-local uint32 indices).
 void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris);

@@ -137,6 +137,23 @@ __device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix,
   return tn <= tf * 1.00002f;
 }
 
+// Slab test on a quantized box (rt_device.h BvhNodeQ): w = lo | hi << 16 per axis; the ray space carries
+// qs = q_scale/d and qb = (q_lo - o)/d, so a plane distance is one cvt + one fma.
+__device__ __forceinline__ bool slab_q(uint32_t wx, uint32_t wy, uint32_t wz, F3 qs, F3 qb, float tmin, float tlim, float& tn) {
+  const float x0 = __builtin_fmaf((float)(wx & 0xFFFFu), qs.x, qb.x), x1 = __builtin_fmaf((float)(wx >> 16), qs.x, qb.x);
+  const float y0 = __builtin_fmaf((float)(wy & 0xFFFFu), qs.y, qb.y), y1 = __builtin_fmaf((float)(wy >> 16), qs.y, qb.y);
+  const float z0 = __builtin_fmaf((float)(wz & 0xFFFFu), qs.z, qb.z), z1 = __builtin_fmaf((float)(wz >> 16), qs.z, qb.z);
+  tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tlim));
+  return tn <= tf * 1.00002f;
+}
+// (qs, qb) of a ray in the space of a tree with dequantisation (q_lo, q_scale)
+__device__ __forceinline__ void quant_space(F3 o, F3 d, const float* q_lo, const float* q_scale, F3& qs, F3& qb) {
+  const F3 id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+  qs = mk3(q_scale[0] * id.x, q_scale[1] * id.y, q_scale[2] * id.z);
+  qb = mk3((q_lo[0] - o.x) * id.x, (q_lo[1] - o.y) * id.y, (q_lo[2] - o.z) * id.z);
+}
+
 // Canonical Moller-Trumbore on one 48-byte packet (see oracle tri_test): two-sided, division-free
 // rejection, one IEEE reciprocal for an accepted candidate, accept iff tmin < t < tmax.
 __device__ __forceinline__ bool tri_test(const float4 T0, const float4 T1, const float4 T2, F3 co, F3 cd, float tmin, float tmax, float& t, float& u, float& v) {
@@ -264,72 +281,149 @@ struct TraceArgs {
 constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
 constexpr int MODE_SHADOW = 1;   // pipeline any hit + shading epilogue
 constexpr int MODE_RAW = 2;      // o.w = tmin, d.w = tmax; writes HitRec
-constexpr int STACK_MARK = 0x7FFFFFFE;  // "return to world space" marker (variant 0)
 
-// ---- variant 0: BVH2, one ray per lane, per-wave LDS stack [entry][lane] (kept as the A/B baseline
-// of the quad kernel; results are identical).  Batches of 64 rays, interleaved over the shards.
+constexpr int REF_DONE = (int)0x80000000;   // bottom-of-stack sentinel: the ray is finished
+constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both negative: not interior)
+
+// ---- variant 0: BVH2, ONE LANE PER RAY, persistent threads with per-lane refill.
+//   * 64-ray chunks from the sharded cursors; the next chunk is in flight into registers while the
+//     current one sits in LDS; idle lanes take rays from LDS by ballot + prefix rank once enough of
+//     them wait (REFILL_MIN), so the wave stays dense without paying the refill code per ray;
+//   * phased loop: the interior-node loop runs while most live lanes are at interior nodes; lanes
+//     that reach a leaf, an instance or the end of their ray wait there, then each of those phases
+//     runs ONCE for all waiting lanes — the expensive, rarer bodies execute densely instead of being
+//     dragged through every trip;
+//   * per-lane stack in LDS [entry][lane] (bank = lane, conflict free), spill to HBM beyond it;
+//   * results staged in LDS and flushed in bursts (stores share the in-order vmcnt with node loads).
+#ifndef RT_REFILL_MIN
+#define RT_REFILL_MIN 16
+#endif
+#ifndef RT_KEEP_NUM
+#define RT_KEEP_NUM 5   /* interior loop continues while >= RT_KEEP_NUM/8 of the live lanes are interior */
+#endif
+#ifndef RT_STACK2_LDS
+#define RT_STACK2_LDS 12   /* 12 entries in LDS (3 KB per wave) let 6 blocks share a CU; deeper paths spill to HBM */
+#endif
+constexpr int STACK2_LDS = RT_STACK2_LDS;
+constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
+
 template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
-  __shared__ int s_stack[4][STACK_LDS][64];
+  __shared__ int s_stack[4][STACK2_LDS][64];
+  __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];
+  __shared__ float4 s_out[4][64];
+  __shared__ int2 s_outq[4][64];
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  int(*stk)[64] = s_stack[wave];
-  int32_t* ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * STACK_OVF;
-  uint32_t cnt[N_SHARDS], maxb = 0;
-#pragma unroll
-  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = a.tails[t * CNT_STRIDE]; maxb = max(maxb, (cnt[t] + 63u) >> 6); }
-  const uint32_t n_waves = gridDim.x * 4u;
-  uint64_t cnt_nodes = 0, cnt_tris = 0;
+  int* const stk = &s_stack[wave][0][lane];                 // entry e at stk[e * 64]
+  int32_t* const ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * STACK_OVF;
+  uint64_t cnt_nodes = 0, cnt_tris = 0, diag_iters = 0, diag_busy = 0;
+  const uint64_t diag_t0 = COUNT ? __builtin_readcyclecounter() : 0;
 
-  for (uint32_t g = blockIdx.x * 4u + wave; g < maxb * N_SHARDS; g += n_waves) {
-    const uint32_t shard = g & (N_SHARDS - 1), base = (g >> 3) << 6;
-    uint32_t n = 0;
-#pragma unroll
-    for (int t = 0; t < N_SHARDS; t++) n = (shard == (uint32_t)t) ? cnt[t] : n;
-    if (base >= n) continue;
-    const uint32_t q = shard * a.shard_cap + base + lane;
-    bool active = base + lane < n;
-    float4 ro = make_float4(0.f, 0.f, 0.f, 0.f), rd = make_float4(0.f, 0.f, 1.f, 0.f);
-    if (active) { ro = a.ray_o[q]; rd = a.ray_d[q]; }
-    float tmin, tmax;
-    uint32_t sid = 0;
-    if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
-    else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
-    const F3 wo = mk3(ro.x, ro.y, ro.z), wd = mk3(rd.x, rd.y, rd.z);
-    F3 co = wo, cd = wd;
-    F3 id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
-    float best_t = tmax, best_u = 0.f, best_v = 0.f;
-    int best_prim = -1, best_inst = -1;
-    int cur_inst = -1;
-    const BvhNode* nodes = a.sc.tlas_nodes;
-    int sp = 0;
-    int cur = 0;               // TLAS root (always interior)
-    bool done = !active;
+  // ---- work distribution (wave-uniform): prefetched chunk in registers, current chunk in LDS
+  uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
+  uint32_t pf_base = 0, pf_count = 0;
+  float4 pf_o = make_float4(0, 0, 0, 0), pf_d = pf_o, pf_c = pf_o;
+  uint32_t chunk_base = 0, chunk_count = 0, chunk_pos = 0;
+  auto prefetch = [&]() {
+    pf_count = 0;
+    while (tried < (uint32_t)N_SHARDS) {
+      const uint32_t size = a.tails[shard * CNT_STRIDE];
+      uint32_t off = 0;
+      if (lane == 0 && size) off = atomicAdd(a.work + shard * CNT_STRIDE, 64u);
+      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+      if (size && off < size) { pf_base = shard * a.shard_cap + off; pf_count = (size - off) < 64u ? (size - off) : 64u; break; }
+      shard = (shard + 1u) & (N_SHARDS - 1); tried++;
+    }
+    if (lane < pf_count) {
+      pf_o = a.ray_o[pf_base + lane]; pf_d = a.ray_d[pf_base + lane];
+      if (MODE == MODE_SHADOW) pf_c = a.sh_c[pf_base + lane];
+    }
+  };
+  auto promote = [&]() {
+    s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
+    if (MODE == MODE_SHADOW) s_rays[wave][2][lane] = pf_c;
+    chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
+    prefetch();
+  };
+  prefetch();
+  promote();
 
-    auto push = [&](int v) {
-      if (sp < STACK_LDS) stk[sp][lane] = v; else ovf[sp - STACK_LDS] = v;
-      sp++;
-    };
-    auto pop = [&]() {
-      for (;;) {
-        if (sp == 0) { done = true; return; }
-        sp--;
-        cur = (sp < STACK_LDS) ? stk[sp][lane] : ovf[sp - STACK_LDS];
-        if (cur != STACK_MARK) return;
-        co = wo; cd = wd;
-        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
-        nodes = a.sc.tlas_nodes; cur_inst = -1;
-      }
-    };
+  uint32_t out_count = 0;
+  auto flush = [&]() {
+    if (lane < out_count) {
+      const float4 r = s_out[wave][lane];
+      const int2 k = s_outq[wave][lane];
+      if (MODE == MODE_CLOSEST) { a.hit_a[k.x] = r; a.hit_inst[k.x] = k.y; }
+      else if (MODE == MODE_SHADOW) a.sample_color[k.x] = r;
+      else { HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = (int)__float_as_uint(r.w); h.inst = k.y; a.raw_out[k.x] = h; }
+    }
+    out_count = 0;
+  };
 
-    while (!done) {
-      if (cur >= 0) {
-        const float4* np = reinterpret_cast<const float4*>(nodes + cur);
-        const float4 A = np[0], B = np[1], C = np[2];
-        const int2 ch = *reinterpret_cast<const int2*>(np + 3);
+  // ---- per-lane ray state
+  bool need = true;
+  uint32_t q = 0, sid = 0;
+  float tmin = 0.f, tmax = 0.f;
+  F3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), co = wo, cd = wd, qs = mk3(1, 1, 1), qb = mk3(0, 0, 0);
+  float4 shc = make_float4(0, 0, 0, 0);
+  float best_t = 0.f, best_u = 0.f, best_v = 0.f;
+  int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
+  const BvhNodeQ* nodes = a.sc.tlas_nodes;
+
+  auto push = [&](int v) {
+    if (sp < STACK2_LDS) stk[sp * 64] = v; else ovf[sp - STACK2_LDS] = v;
+    sp++;
+  };
+  auto pop = [&]() {
+    sp--;
+    if (sp < STACK2_LDS) cur = stk[sp * 64]; else cur = ovf[sp - STACK2_LDS];
+  };
+
+  for (;;) {
+    // ---- (A) refill
+    const uint64_t need_mask = __ballot(need);
+    const uint32_t n_need = (uint32_t)__builtin_popcountll(need_mask);
+    if (n_need >= REFILL_MIN || n_need == 64u) {
+      if (chunk_pos == chunk_count && pf_count > 0) promote();
+      if (chunk_pos < chunk_count) {
+        const uint32_t rank = prefix_rank(need_mask);
+        const uint32_t avail = chunk_count - chunk_pos;
+        if (need && rank < avail) {
+          const uint32_t ci = chunk_pos + rank;
+          q = chunk_base + ci;
+          const float4 ro = s_rays[wave][0][ci], rd = s_rays[wave][1][ci];
+          if (MODE == MODE_SHADOW) shc = s_rays[wave][2][ci];
+          if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
+          else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
+          wo = mk3(ro.x, ro.y, ro.z); wd = mk3(rd.x, rd.y, rd.z);
+          co = wo; cd = wd;
+          quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
+          best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
+          cur_inst = -1; nodes = a.sc.tlas_nodes;
+          stk[0] = REF_DONE; sp = 1;
+          cur = 0;   // TLAS root (always interior)
+          need = false;
+        }
+        chunk_pos += n_need < avail ? n_need : avail;
+      } else if (n_need == 64u) { flush(); break; }   // queue drained and every lane idle
+    }
+    const uint32_t live = 64u - (uint32_t)__builtin_popcountll(__ballot(need));
+    const uint32_t keep_going = (live * RT_KEEP_NUM + 7u) >> 3;   // share of the live lanes that must still be interior
+
+    // ---- (B) interior-node loop: runs while most live lanes are at interior nodes
+    for (;;) {
+      const bool interior = !need && cur >= 0;
+      const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(interior));
+      if (n_int == 0 || n_int < keep_going) break;
+      if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
+      if (interior) {
+        const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);   // 32-byte node: two requests
+        const uint4 Q0 = np[0], Q1 = np[1];
+        const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
-        const bool h0 = slab(A.x, A.z, C.x, A.y, A.w, C.y, co, id, tmin, best_t, t0);
-        const bool h1 = slab(B.x, B.z, C.z, B.y, B.w, C.w, co, id, tmin, best_t, t1);
+        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, tmin, best_t, t0);
+        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, tmin, best_t, t1);
         if (h0 && h1) {
           const bool swap = t1 < t0;
           push(swap ? ch.x : ch.y);
@@ -337,20 +431,35 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
         } else if (h0) cur = ch.x;
         else if (h1) cur = ch.y;
         else pop();
+      }
+    }
+
+    // ---- (C) the rarer bodies, each run once for all lanes that wait at them
+    if (!need && cur < 0 && cur != REF_DONE) {
+      if (cur == REF_MARK) {
+        // leave the instance: back to the world-space ray and the TLAS
+        co = wo; cd = wd;
+        quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
+        nodes = a.sc.tlas_nodes; cur_inst = -1;
+        pop();
       } else if (cur_inst < 0) {
+        // TLAS leaf: enter the instance (ray -> object space, t preserved)
         const int ii = ~cur;
         const InstanceDev* I = a.sc.inst + ii;
-        if ((I->mask & 0xFFu) == 0u) { pop(); continue; }
-        float m[12];
-        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
-        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
-        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
-        co = xform_point(m, wo); cd = xform_vec(m, wd);
-        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
-        push(STACK_MARK);
-        cur_inst = ii; nodes = a.sc.blas_nodes; cur = I->blas_root;
+        if ((I->mask & 0xFFu) == 0u) pop();
+        else {
+          float m[12];
+          const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+          float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+          m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+          m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
+          co = xform_point(m, wo); cd = xform_vec(m, wd);
+          quant_space(co, cd, I->q_lo, I->q_scale, qs, qb);
+          push(REF_MARK);
+          cur_inst = ii; nodes = a.sc.blas_nodes; cur = I->blas_root;
+        }
       } else {
+        // BLAS leaf: Moller-Trumbore on 48-byte packets
         const uint32_t ref = (uint32_t)(~cur);
         const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
         for (uint32_t k = 0; k < count; k++) {
@@ -365,25 +474,32 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
             if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
           }
         }
-        if (ANY && best_inst >= 0) { done = true; }
+        if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
         else pop();
       }
     }
 
-    if (active) {
-      if (MODE == MODE_CLOSEST) {
-        a.hit_a[q] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
-        a.hit_inst[q] = best_inst;
-      } else if (MODE == MODE_SHADOW) {
-        const float4 c = a.sh_c[q];
-        float r = 0.08f, g2 = 0.24f, b = 0.08f;
-        if (best_inst < 0) { r = __builtin_fmaf(c.w, c.x, r); g2 = __builtin_fmaf(c.w, c.y, g2); b = __builtin_fmaf(c.w, c.z, b); }
-        a.sample_color[sid] = make_float4(r, g2, b, 1.0f);
-      } else {
-        HitRec h;
-        h.t = best_t; h.u = best_u; h.v = best_v; h.prim = best_prim; h.inst = best_inst;
-        a.raw_out[q] = h;
+    // ---- (D) finished rays: append the result to the wave's LDS out-list
+    const bool fin = !need && cur == REF_DONE;
+    const uint64_t fin_mask = __ballot(fin);
+    if (fin_mask != 0) {
+      const uint32_t n_fin = (uint32_t)__builtin_popcountll(fin_mask);
+      if (out_count + n_fin > 64u) flush();   // the out-list holds 64 results
+      if (fin) {
+        const uint32_t slot = out_count + prefix_rank(fin_mask);
+        if (MODE == MODE_SHADOW) {
+          // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
+          float r = 0.08f, g = 0.24f, b = 0.08f;
+          if (best_inst < 0) { r = __builtin_fmaf(shc.w, shc.x, r); g = __builtin_fmaf(shc.w, shc.y, g); b = __builtin_fmaf(shc.w, shc.z, b); }
+          s_out[wave][slot] = make_float4(r, g, b, 1.0f);
+          s_outq[wave][slot] = make_int2((int)sid, 0);
+        } else {
+          s_out[wave][slot] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
+          s_outq[wave][slot] = make_int2((int)q, best_inst);
+        }
+        need = true;
       }
+      out_count += n_fin;
     }
   }
   if (COUNT) {
@@ -395,6 +511,10 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
       const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
       atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
       atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
+      const int dg = ANY ? CNT_DIAG_SH : CNT_DIAG;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg), (unsigned long long)diag_iters);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 2), (unsigned long long)diag_busy);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 4), (unsigned long long)(__builtin_readcyclecounter() - diag_t0));
     }
   }
 }
@@ -417,7 +537,8 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
 // active.  Results are identical to k_trace: same triangle arithmetic, same tie rule.
 constexpr int QP_ROT1 = 0x39, QP_ROT2 = 0x4E, QP_ROT3 = 0x93, QP_SWAP1 = 0xB1, QP_SWAP2 = 0x4E;
 template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
+  // every source lane of a quad_perm is active here (control flow is quad-uniform), so no `old` value is needed
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
 }
 __device__ __forceinline__ uint32_t quad_or(uint32_t v) { v |= dpp_u<QP_SWAP1>(v); v |= dpp_u<QP_SWAP2>(v); return v; }
 __device__ __forceinline__ float quad_minf(float v) {
@@ -431,8 +552,31 @@ __device__ __forceinline__ int quad_mini(int v) {
   return v;
 }
 
-constexpr int REF_DONE = (int)0x80000000;   // bottom-of-stack sentinel: the ray is finished
-constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both negative: not interior)
+// Slab test of the quad kernel: six v_fma_f32 evaluate the plane distances as t = plane*(1/d) + (-o/d).
+// (Deliberately NOT v_pk_fma_f32: packed f32 math issues far slower than two scalar fmas on gfx950 —
+// measured here as +45 % on the shadow kernel — and the file is built with -fno-slp-vectorize for the
+// same reason.)  The product o/d is rounded once per ray space, so an absolute slack proportional to
+// |o/d| joins the relative one; the test stays conservative, never canonical.
+struct RaySpace {
+  F3 id;   // 1/d
+  F3 n;    // -o/d
+  float abs_slack;
+};
+__device__ __forceinline__ RaySpace make_space(F3 o, F3 d) {
+  RaySpace r;
+  r.id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
+  r.n = mk3(-(o.x * r.id.x), -(o.y * r.id.y), -(o.z * r.id.z));
+  r.abs_slack = 4e-7f * fmaxf(fmaxf(__builtin_fabsf(r.n.x), __builtin_fabsf(r.n.y)), __builtin_fabsf(r.n.z));
+  return r;
+}
+__device__ __forceinline__ bool slab4(const float4 A, const float4 B, const RaySpace& rs, float tmin, float tlim, float& tn) {
+  const float x0 = __builtin_fmaf(A.x, rs.id.x, rs.n.x), x1 = __builtin_fmaf(A.w, rs.id.x, rs.n.x);
+  const float y0 = __builtin_fmaf(A.y, rs.id.y, rs.n.y), y1 = __builtin_fmaf(B.x, rs.id.y, rs.n.y);
+  const float z0 = __builtin_fmaf(A.z, rs.id.z, rs.n.z), z1 = __builtin_fmaf(B.y, rs.id.z, rs.n.z);
+  tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tlim));
+  return tn <= __builtin_fmaf(tf, 1.00002f, rs.abs_slack);
+}
 
 template <int MODE, bool ANY, bool COUNT>
 __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
@@ -445,7 +589,9 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
   const uint32_t sub = lane & 3u, ray = lane >> 2;
   int(*stk)[16] = s_stack[wave];
   const uint32_t KEY_MISS = 0xFFFFFFF0u;
-  const Bvh4Node* const nodes = a.sc.nodes4;   // BLAS nodes followed by the TLAS nodes: one base pointer
+  const char* const node_bytes = reinterpret_cast<const char*>(a.sc.nodes4);   // BLAS nodes then TLAS nodes: one base
+  const uint32_t lane_off = sub * 32u, quad_shift = lane & ~3u;
+  int* const stk_ray = &stk[0][ray];
   uint64_t cnt_nodes = 0, cnt_tris = 0;
 
   // ---- work distribution (wave-uniform): prefetched chunk in registers, current chunk in LDS
@@ -481,7 +627,8 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
   bool need = true;
   uint32_t q = 0, sid = 0;
   float tmin = 0.f, tmax = 0.f;
-  F3 co = mk3(0, 0, 0), cd = mk3(0, 0, 1), id = mk3(1, 1, 1);
+  F3 co = mk3(0, 0, 0), cd = mk3(0, 0, 1);
+  RaySpace rs = make_space(co, cd);
   float4 shc = make_float4(0, 0, 0, 0);
   float best_t = 0.f, best_u = 0.f, best_v = 0.f;
   int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
@@ -519,7 +666,7 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
           else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
           if (sub == 0) { s_world[wave][0][ray] = ro; s_world[wave][1][ray] = rd; }
           co = mk3(ro.x, ro.y, ro.z); cd = mk3(rd.x, rd.y, rd.z);
-          id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+          rs = make_space(co, cd);
           best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
           cur_inst = -1;
           stk[0][ray] = REF_DONE; sp = 1;
@@ -534,31 +681,46 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
 
     // ---- (B) interior steps: stay in this loop while the quad's node is interior
     while (cur >= 0) {
-      const float4* cp = reinterpret_cast<const float4*>(nodes + cur) + sub * 2u;
+      const uint32_t off = ((uint32_t)cur << 7) + lane_off;        // 128-byte node, 32-byte child record
+      const float4* cp = reinterpret_cast<const float4*>(node_bytes + off);
       const float4 A = cp[0], B = cp[1];
-      if (COUNT) { if (sub == 0) cnt_nodes++; if (lane == 0) diag_iters++; }
+      if (COUNT) { if (sub == 0) cnt_nodes++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) diag_iters++; }
       float tn;
-      const bool hit = slab(A.x, A.y, A.z, A.w, B.x, B.y, co, id, tmin, best_t, tn);
+#ifdef RT_EXP_FMA_SLAB
+      const bool hit = slab4(A, B, rs, tmin, best_t, tn);
+#else
+      // sub-mul form: measured faster than the fma form on the any-hit kernel (0.76 vs 1.13 ms) and exact at o == plane
+      const bool hit = slab(A.x, A.y, A.z, A.w, B.x, B.y, co, rs.id, tmin, best_t, tn);
+#endif
       const int ref = (int)__float_as_uint(B.z);
+      // hit children of this quad: 4 bits of the wave ballot
+#ifdef RT_EXP_OLD_NH
+      const int nh_dummy = 0; (void)nh_dummy;
+#else
+      const uint32_t qbits = (uint32_t)(__ballot(hit) >> quad_shift) & 0xFu;
+      const int nh = __builtin_popcount(qbits);
+#endif
       const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | sub) : (KEY_MISS | sub);
       const uint32_t k1 = dpp_u<QP_ROT1>(key), k2 = dpp_u<QP_ROT2>(key), k3 = dpp_u<QP_ROT3>(key);
       const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
+#ifdef RT_EXP_OLD_NH
       const int nh = (int)(k1 < KEY_MISS) + (int)(k2 < KEY_MISS) + (int)(k3 < KEY_MISS) + (int)hit;
+#endif
       const uint32_t nearest = quad_or((hit && rank == 0) ? (uint32_t)ref : 0u);
-      if (hit && rank > 0) stk[sp + nh - 1 - rank][ray] = ref;   // farthest child deepest
-      if (nh == 0) { sp--; cur = stk[sp][ray]; }
+      if (hit && rank > 0) stk_ray[(sp + nh - 1 - rank) * 16] = ref;   // farthest child deepest
+      if (nh == 0) { sp--; cur = stk_ray[sp * 16]; }
       else { cur = (int)nearest; sp += nh - 1; }
     }
 
     // ---- (C) the node is not interior: finished, leave-instance marker, TLAS leaf or BLAS leaf
-    if (COUNT && lane == 0) { diag_busy++; }
+    if (COUNT && lane == (uint32_t)__builtin_ctzll(__ballot(true))) { diag_busy++; }
     if (cur == REF_DONE) {
       // handled below at a wave-uniform point
     } else if (cur == REF_MARK) {
       // leave the instance: world-space ray back from LDS
       const float4 ro = s_world[wave][0][ray], rd = s_world[wave][1][ray];
       co = mk3(ro.x, ro.y, ro.z); cd = mk3(rd.x, rd.y, rd.z);
-      id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+      rs = make_space(co, cd);
       cur_inst = -1;
       sp--; cur = stk[sp][ray];
     } else if (cur_inst < 0) {
@@ -574,7 +736,7 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
         m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
         const F3 wo = co, wd = cd;
         co = xform_point(m, wo); cd = xform_vec(m, wd);
-        id = mk3(safe_rcp(cd.x), safe_rcp(cd.y), safe_rcp(cd.z));
+        rs = make_space(co, cd);
         stk[sp][ray] = REF_MARK; sp++;
         cur_inst = ii; cur = I->blas_root4;
       }
@@ -634,6 +796,10 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
     for (int off = 32; off > 0; off >>= 1) {
       cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
       cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      diag_iters += __shfl_down((unsigned long long)diag_iters, off);
+      diag_busy += __shfl_down((unsigned long long)diag_busy, off);
     }
     if (lane == 0) {
       const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;

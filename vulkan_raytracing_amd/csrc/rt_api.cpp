@@ -35,6 +35,8 @@ struct Mesh {
   bool built = false;
   BuiltBvh bvh;
   Bvh4 bvh4;
+  std::vector<BvhNodeQ> qnodes;   // quantized form of bvh.nodes
+  float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
   std::vector<TriPacket> tris;
   int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays
   uint32_t tri_base = 0;
@@ -59,7 +61,7 @@ struct rt_ctx {
   uint32_t* d_idx = nullptr;
   std::vector<Mesh> meshes;
   bool blas_linked = false;
-  BvhNode* d_blas_nodes = nullptr;
+  BvhNodeQ* d_blas_nodes = nullptr;
   Bvh4Node* d_nodes4 = nullptr;     // BLAS BVH4 nodes followed by the TLAS BVH4 nodes
   size_t cap_nodes4 = 0, n_blas4 = 0;
   std::vector<Bvh4Node> h_blas4;
@@ -73,7 +75,8 @@ struct rt_ctx {
   Bvh4 tlas4;
   bool tlas_valid = false;
   InstanceDev* d_inst = nullptr;
-  BvhNode* d_tlas_nodes = nullptr;
+  BvhNodeQ* d_tlas_nodes = nullptr;
+  float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
   size_t cap_inst = 0, cap_tlas_nodes = 0;
 
   // uniforms (binding 1), cube map (binding 5)
@@ -162,13 +165,14 @@ int link_blas(rt_ctx* c) {
     m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt; m.node_base4 = (int32_t)nn4;
     nn += m.bvh.nodes.size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
   }
-  std::vector<BvhNode> nodes(nn);
+  std::vector<BvhNodeQ> nodes(nn);
   std::vector<Bvh4Node> nodes4(nn4);
   std::vector<TriPacket> tris(nt);
   for (auto& m : c->meshes) {
     if (!m.built) continue;
-    for (size_t i = 0; i < m.bvh.nodes.size(); i++) {
-      BvhNode n = m.bvh.nodes[i];
+    quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
+    for (size_t i = 0; i < m.qnodes.size(); i++) {
+      BvhNodeQ n = m.qnodes[i];
       auto fix = [&](int32_t ch) -> int32_t {
         if (ch >= 0) return ch + m.node_base;
         uint32_t ref = (uint32_t)(~ch);
@@ -194,9 +198,9 @@ int link_blas(rt_ctx* c) {
   if (c->d_tris) { HIP_TRY(c, hipFree(c->d_tris)); c->d_tris = nullptr; }
   if (c->d_nodes4) { HIP_TRY(c, hipFree(c->d_nodes4)); c->d_nodes4 = nullptr; c->cap_nodes4 = 0; }
   c->h_blas4.swap(nodes4); c->n_blas4 = nn4;
-  HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, std::max<size_t>(1, nn) * sizeof(BvhNode)));
+  HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, std::max<size_t>(1, nn) * sizeof(BvhNodeQ)));
   HIP_TRY(c, hipMalloc((void**)&c->d_tris, std::max<size_t>(1, nt) * sizeof(TriPacket)));
-  if (nn) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, nodes.data(), nn * sizeof(BvhNode), hipMemcpyHostToDevice));
+  if (nn) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, nodes.data(), nn * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
   if (nt) HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriPacket), hipMemcpyHostToDevice));
   c->n_blas_nodes = nn; c->n_tris = nt;
   c->blas_linked = true;
@@ -212,7 +216,7 @@ int upload_instances(rt_ctx* c) {
   }
   if (c->tlas.nodes.size() > c->cap_tlas_nodes) {
     if (c->d_tlas_nodes) HIP_TRY(c, hipFree(c->d_tlas_nodes));
-    HIP_TRY(c, hipMalloc((void**)&c->d_tlas_nodes, c->tlas.nodes.size() * sizeof(BvhNode)));
+    HIP_TRY(c, hipMalloc((void**)&c->d_tlas_nodes, c->tlas.nodes.size() * sizeof(BvhNodeQ)));
     c->cap_tlas_nodes = c->tlas.nodes.size();
   }
   // stream-ordered so a per-frame update never stalls the host on a fence (the reference blocks on
@@ -231,7 +235,9 @@ int upload_instances(rt_ctx* c) {
     for (int k = 0; k < 4; k++)
       if (nd.c[k].ref >= 0 && nd.c[k].ref != 0x7FFFFFFF) nd.c[k].ref += (int32_t)c->n_blas4;
   HIP_TRY(c, hipMemcpyAsync(c->d_nodes4 + c->n_blas4, t4.data(), t4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipMemcpyAsync(c->d_tlas_nodes, c->tlas.nodes.data(), c->tlas.nodes.size() * sizeof(BvhNode), hipMemcpyHostToDevice, c->stream));
+  std::vector<BvhNodeQ> tq;
+  quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
+  HIP_TRY(c, hipMemcpyAsync(c->d_tlas_nodes, tq.data(), tq.size() * sizeof(BvhNodeQ), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rewritten by the next call
   return RT_OK;
 }
@@ -242,6 +248,7 @@ SceneDev scene_dev(const rt_ctx* c) {
   s.blas_nodes = c->d_blas_nodes; s.tris = c->d_tris; s.tlas_nodes = c->d_tlas_nodes; s.inst = c->d_inst;
   s.verts = c->d_verts; s.idx = c->d_idx; s.sky = c->d_sky; s.n_inst = (int)c->h_inst_dev.size();
   s.sky_w = c->sky_w; s.sky_h = c->sky_h;
+  for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
   return s;
 }
 
@@ -355,7 +362,7 @@ int collect_stats(rt_ctx* c) {
   memcpy(&st.tri_tests_shadow, &cnt[CNT_TRI_TESTS_SH], 8);
   memcpy(&st.diag[0], &cnt[CNT_DIAG], 24);
   memcpy(&st.diag[3], &cnt[CNT_DIAG_SH], 24);
-  st.bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNode); st.bvh_tri_bytes = sizeof(TriPacket);
+  st.bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNodeQ); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
@@ -399,10 +406,11 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   c->n_cu = prop.multiProcessorCount;
   c->info = std::string("gfx950 ") + prop.name + " CUs=" + std::to_string(prop.multiProcessorCount);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_DEVICE, "hipStreamCreate failed"); }
-  // persistent grids: LDS stacks (24 KB per 256-thread block) admit 6 blocks per CU
+  // persistent grids: ~27 KB of LDS and <= 84 VGPRs per 256-thread block admit 5-6 blocks per CU
   c->cfg.trace_blocks = c->n_cu * 6;
   c->cfg.shade_blocks = c->n_cu * 8;
-  c->cfg.variant = 1;
+  // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
+  c->cfg.variant = 0;
   if (const char* env = getenv("RT_TRACE_VARIANT")) c->cfg.variant = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   *out_ctx = c;
@@ -486,11 +494,12 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     invert_affine(d.o2w, d.w2o);
     d.blas_root = m.node_base;
     d.blas_root4 = m.node_base4;
-    d.mask = inst[i].custom_index_and_mask >> 24;
+    d.mask = m.range.prim_count ? (inst[i].custom_index_and_mask >> 24) : 0u;   // an empty mesh is never entered
+    for (int k = 0; k < 3; k++) { d.q_lo[k] = m.q_lo[k]; d.q_scale[k] = m.q_scale[k]; }
     d.custom_index = (int32_t)(inst[i].custom_index_and_mask & 0xFFFFFFu);
     d.first_float = (uint32_t)m.range.first_float;
     d.first_index = (uint32_t)m.range.first_index;
-    d.pad[0] = d.pad[1] = 0;
+    d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0;
     boxes[i] = instance_world_box(d.o2w, m.bvh.bounds);
   }
   if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
@@ -641,7 +650,7 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     if (any_hit) stats->ms_trace_shadow = ms; else stats->ms_trace_closest = ms;
     stats->closest_rays = any_hit ? 0 : n; stats->rays_shadow = any_hit ? n : 0;
-    stats->bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNode); stats->bvh_tri_bytes = sizeof(TriPacket);
+    stats->bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNodeQ); stats->bvh_tri_bytes = sizeof(TriPacket);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
   hipFree(d_o); hipFree(d_d); hipFree(d_h);

@@ -22,6 +22,20 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 64, "BvhNode must be 64 bytes");
 
+// Quantized BVH2 node, 32 B = TWO 16-byte requests per lane and visit instead of four.  The one-lane-
+// per-ray kernel is bound by the CU's vector-memory address unit (one divergent 16-byte lane request
+// per cycle), so halving the requests per visit is worth more than anything arithmetic.
+// Planes are 16-bit fixed point inside the bounds of their tree (mesh bounds for a BLAS, instance
+// bounds for the TLAS): plane = q_lo + q * q_scale, lower planes rounded down and upper planes
+// rounded up by a full quantum, so a quantized box always contains the float box.  The slab test
+// never decodes a plane: t = q * (q_scale/d) + (q_lo - o)/d, one cvt + one fma per plane.
+//   w0 = c0.lo.x | c0.hi.x << 16   w1 = c0 y   w2 = c0 z   w3 = c1 x   w4 = c1 y   w5 = c1 z   w6, w7 = links
+struct alignas(16) BvhNodeQ {
+  uint32_t w[6];
+  int32_t child0, child1;
+};
+static_assert(sizeof(BvhNodeQ) == 32, "BvhNodeQ must be 32 bytes");
+
 // BVH4 node for the quad-cooperative traversal (4 lanes per ray): 128 B = one cache line, child k at
 // byte 32k so that the 4 lanes of a quad read 4 consecutive 32-byte records (2 x dwordx4 each).
 //   (lo.x, lo.y, lo.z, hi.x) (hi.y, hi.z, ref, 0);  ref as in BvhNode::child*; a missing child is the
@@ -49,7 +63,7 @@ struct alignas(16) TriPacket {
 };
 static_assert(sizeof(TriPacket) == 48, "TriPacket must be 48 bytes");
 
-// Per-instance record, 128 B.
+// Per-instance record, 160 B.
 struct alignas(16) InstanceDev {
   float w2o[12];        // gl_WorldToObjectEXT, row-major 3x4 (inverse evaluated in binary64, rounded once)
   float o2w[12];        // gl_ObjectToWorldEXT, row-major 3x4 (rt_instance::transform)
@@ -58,10 +72,12 @@ struct alignas(16) InstanceDev {
   int32_t custom_index; // gl_InstanceCustomIndexEXT
   uint32_t first_float; // vertexOffset of src/shader.rchit:55 (floats)
   uint32_t first_index; // 3*primitive offset of src/shader.rchit:54 (uint32s)
-  int32_t blas_root4;   // root of the mesh in blas_nodes4 (BVH4)
-  uint32_t pad[2];
+  int32_t blas_root4;   // root of the mesh in nodes4 (BVH4)
+  float q_lo[3];        // dequantisation of the mesh's BvhNodeQ planes (object space)
+  float q_scale[3];
+  uint32_t pad[4];
 };
-static_assert(sizeof(InstanceDev) == 128, "InstanceDev must be 128 bytes");
+static_assert(sizeof(InstanceDev) == 160, "InstanceDev must be 160 bytes");
 
 // Mirror of rt_uniforms / UniformStructure (104 B), passed to kernels by value.
 struct UniformsDev {

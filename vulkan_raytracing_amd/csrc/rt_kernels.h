@@ -8,9 +8,10 @@
 namespace rt {
 
 struct SceneDev {
-  const BvhNode* blas_nodes;
+  const BvhNodeQ* blas_nodes;  // variant 0: quantized BVH2 nodes of all meshes
   const float4* tris;          // 3 float4 per TriPacket
-  const BvhNode* tlas_nodes;
+  const BvhNodeQ* tlas_nodes;  // variant 0: quantized TLAS nodes
+  float tlas_q_lo[3], tlas_q_scale[3];
   const Bvh4Node* nodes4;      // quad traversal (variant 1): BLAS BVH4 nodes, then the TLAS BVH4 nodes
   int tlas_root4;              // index of the TLAS root in nodes4
   const InstanceDev* inst;
