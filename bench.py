@@ -6,7 +6,8 @@ supplied) + skybox_texture_sea, 1920x1080, depth 4 (maxBounceCount 3) + shadow r
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU.  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
+One process per GPU, --frames-in-flight (3) independent frames in flight per GPU (the reference's swapchain
+keeps minImageCount + 1 frames in flight, src/main.cpp:1203, 2967).  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
 x 4 bounces -> any-hit shadow traversal -> resolve, on this rank's interleaved 8-row bands, followed
 (N > 1) by ONE RCCL gather of the compact shards to rank 0 and the row permutation that reassembles
 the frame.  The frame is fixed, so scaling is STRONG.  Inputs (scene, BVH, cube map) are resident in
@@ -84,8 +85,11 @@ def cpu_baseline(geom, inst, u, sky, budget_s=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--frames-in-flight", type=int, default=3,
+                    help="independent frames in flight per GPU, each on its own stream and buffers; the reference keeps "
+                         "swapchainImageCount = minImageCount + 1 frames in flight (src/main.cpp:1203, 2790, 2905-2967)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
     ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray")
@@ -107,23 +111,30 @@ def main():
     dev = torch.device("cuda", local_rank)
     n = world
     assert args.gpus == n, "--gpus must equal the number of launched ranks"
+    P = max(1, args.frames_in_flight)
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
         host.armadillo_path(res)  # generate the stand-in once before the other ranks look for it
     if n > 1:
         dist.barrier()
-    ctx = RtContext(local_rank)
-    geom, inst, u, sky, arm_label = build_scene(ctx, res)
-    if args.variant is not None:
-        ctx.set_param("trace_variant", args.variant)
-    if args.blocks_per_cu is not None:
-        ctx.set_param("trace_blocks_per_cu", args.blocks_per_cu)
+    # one context (scene replica, queues, counters) per frame in flight — the analogue of the reference's
+    # per-swapchain-image command buffer, fence and semaphores (src/main.cpp:2597, 2740-2749)
+    ctxs = []
+    for _ in range(P):
+        c = RtContext(local_rank)
+        geom, inst, u, sky, arm_label = build_scene(c, res)
+        if args.variant is not None:
+            c.set_param("trace_variant", args.variant)
+        if args.blocks_per_cu is not None:
+            c.set_param("trace_blocks_per_cu", args.blocks_per_cu)
+        ctxs.append(c)
+    ctx = ctxs[0]
 
     band = tiling.BAND_ROWS
     rows_max = tiling.max_shard_rows(HEIGHT, band, n)
-    shard = torch.zeros((rows_max, WIDTH, 4), dtype=torch.float32, device=dev)
-    gathered = torch.zeros((n, rows_max, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and n > 1) else None
+    shards = [torch.zeros((rows_max, WIDTH, 4), dtype=torch.float32, device=dev) for _ in range(P)]
+    gathered = [torch.zeros((n, rows_max, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and n > 1) else None for _ in range(P)]
     perm = None
     if rank == 0 and n > 1:
         src = np.zeros(HEIGHT, np.int64)
@@ -131,26 +142,31 @@ def main():
             m = tiling.shard_row_map(HEIGHT, band, s, n)
             src[m] = s * rows_max + np.arange(len(m))
         perm = torch.as_tensor(src, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    frame = None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+    frames = [None] * P
+    counter = [0]
 
     def step():
-        nonlocal frame
-        ctx.trace_shard(WIDTH, HEIGHT, band, rank, n, shard.data_ptr(), shard.numel() * 4, stream.cuda_stream)
-        if n > 1:
-            dist.gather(shard, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
-            if rank == 0:
-                frame = gathered.view(n * rows_max, WIDTH, 4).index_select(0, perm)
-        else:
-            frame = shard
+        j = counter[0] % P
+        counter[0] += 1
+        with torch.cuda.stream(streams[j]):
+            ctxs[j].trace_shard(WIDTH, HEIGHT, band, rank, n, shards[j].data_ptr(), shards[j].numel() * 4, streams[j].cuda_stream)
+            if n > 1:
+                dist.gather(shards[j], list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
+                if rank == 0:
+                    frames[j] = gathered[j].view(n * rows_max, WIDTH, 4).index_select(0, perm)
+            else:
+                frames[j] = shards[j]
 
     def sync():
+        for s_ in streams:
+            s_.synchronize()
         torch.cuda.synchronize(dev)
         if n > 1:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    ctx.set_timing(True)   # HIP events around every kernel, on the stream the kernels run on
+    ctx.set_timing(True)   # HIP events around every kernel of context 0's frames (every P-th frame), on their own stream
     for _ in range(args.warmup):
         step()
     sync()
@@ -159,7 +175,7 @@ def main():
         step()
     sync()
     dt = time.perf_counter() - t0
-    st = ctx.stats()        # counters + event times of the LAST timed frame (all frames are identical)
+    st = ctx.stats()        # counters + event times of context 0's LAST timed frame (all frames are identical)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_secondary, st.rays_shadow], dtype=torch.float64, device=dev)
     if n > 1:
@@ -179,39 +195,50 @@ def main():
                   "config": {"workload": "BASELINE cfg3: teapot.obj mirror + %s diffuse, skybox_texture_sea, %dx%d, maxBounceCount %d (depth 4) + shadow rays, spp %d"
                                          % (arm_label, WIDTH, HEIGHT, MAX_BOUNCE, SPP),
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
-                             "parallelism": "interleaved %d-row bands over %d GPU(s), scene replicated, one RCCL gather per frame" % (band, n),
-                             "device": ctx.device_info}}
+                             "parallelism": "interleaved %d-row bands over %d GPU(s), scene replicated, one RCCL gather per frame, %d frames in flight per GPU" % (band, n, P),
+                             "frames_in_flight": P, "device": ctx.device_info}}
     # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's shard -----------------
-    ctx.set_timing(False)
     if rank == 0:
-        # mean node visits / triangle tests per ray from the instrumented build of the same kernel over
-        # the full frame (exact for n == 1; for n > 1 rank 0's bands are an interleaved sample of it)
+        # (1) isolated frames: the same shard, one frame at a time on context 0, HIP events around every kernel
+        iso = []
+        for _ in range(5):
+            ctx.trace_shard(WIDTH, HEIGHT, band, rank, n, shards[0].data_ptr(), shards[0].numel() * 4, streams[0].cuda_stream)
+            iso.append(ctx.stats())
+        iso_ms = sorted(x.ms_trace_closest for x in iso)[len(iso) // 2]
+        ctx.set_timing(False)
+        # (2) mean node visits / triangle tests per ray from the instrumented build of the same kernel over the
+        # full frame (exact for n == 1; for n > 1 rank 0's bands are an interleaved sample of it)
         _, cst = ctx.trace(WIDTH, HEIGHT, counting=True)
         mean_nodes = cst.node_visits / max(1, cst.closest_rays)
         mean_tris = cst.tri_tests / max(1, cst.closest_rays)
         closest_rays_rank0 = st.closest_rays   # rays that entered the traversal kernel (survivors of the TLAS-root test + secondary)
         alg_bytes = closest_rays_rank0 * (RAY_BYTES + HIT_BYTES + mean_nodes * cst.bvh_node_bytes + mean_tris * cst.bvh_tri_bytes)
         launches = max(1, st.launches_trace_closest)
-        t_kernel_s = st.ms_trace_closest * 1e-3
-        achieved = alg_bytes / t_kernel_s / 1e9 if t_kernel_s > 0 else 0.0
+        live_s = st.ms_trace_closest * 1e-3
+        achieved = alg_bytes / live_s / 1e9 if live_s > 0 else 0.0
+        achieved_iso = alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": None,
                               "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore",
                               "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
                               "algorithmic_bytes_per_launch": alg_bytes / launches,
+                              "timing": "HIP events on the kernel's own stream, live in the timed region (context 0's last frame); with %d frames in flight the kernel "
+                                        "shares the GPU with the kernels of the other frames, so its launch duration is longer than when it runs alone" % P,
+                              "isolated": {"achieved": achieved_iso, "frac": achieved_iso / HBM_PEAK_GBS, "avg_launch_ms": iso_ms / launches,
+                                           "timing": "median of 5 frames run one at a time right after the timed region (same process, same buffers)"},
                               "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,
                               "node_bytes": cst.bvh_node_bytes, "tri_bytes": cst.bvh_tri_bytes,
                               "frame_kernel_ms": {"raygen": st.ms_raygen, "trace_closest": st.ms_trace_closest, "shade": st.ms_shade,
                                                   "trace_shadow": st.ms_trace_shadow, "resolve": st.ms_resolve, "frame": st.ms_frame},
-                              "note": "scene (BVH+triangles ~40 MB) and cube map (96 MiB) fit the 256 MiB Infinity Cache: HBM traffic << algorithmic bytes"}
+                              "note": "scene (BVH+triangles ~25 MB) and cube map (96 MiB) fit the 256 MiB Infinity Cache: HBM traffic << algorithmic bytes"}
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         if os.path.exists(traffic_file):
             try:
                 result["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        if args.save_image and frame is not None:
-            img = frame[:HEIGHT].cpu().numpy()
+        if args.save_image and frames[0] is not None:
+            img = frames[0][:HEIGHT].cpu().numpy()
             with open(args.save_image, "wb") as fh:
                 fh.write(b"PF4\n%d %d\n-1.0\n" % (WIDTH, HEIGHT))
                 fh.write(img[::-1].astype("<f4").tobytes())
@@ -223,7 +250,8 @@ def main():
     if n > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c in ctxs:
+        c.close()
 
 
 if __name__ == "__main__":

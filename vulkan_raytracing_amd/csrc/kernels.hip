@@ -276,6 +276,8 @@ struct TraceArgs {
   int32_t* ovf_stack;
   uint32_t* counters;
   float tmin;
+  uint32_t rays_per_lane;      // device-side grid sizing (variant 0): blocks beyond total/(256*rays_per_lane) exit
+  uint32_t min_blocks;
 };
 
 constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
@@ -313,6 +315,18 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
+  // Grid sizing on the device: the launch always has the full persistent grid, but a queue that holds only a
+  // few rays per lane runs faster on fewer, less contended waves that refill (every ray costs ~25-40 dependent
+  // trips, and a trip is quickest with 1-2 waves per SIMD) — surplus blocks leave at once.
+  {
+    uint32_t total = 0;
+#pragma unroll
+    for (int t = 0; t < N_SHARDS; t++) total += a.tails[t * CNT_STRIDE];
+    uint32_t want = (total + 256u * a.rays_per_lane - 1u) / (256u * a.rays_per_lane);
+    want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
+    if (want < a.min_blocks) want = a.min_blocks;
+    if (blockIdx.x >= want) return;
+  }
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   int* const stk = &s_stack[wave][0][lane];                 // entry e at stk[e * 64]
   int32_t* const ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * STACK_OVF;
@@ -368,15 +382,17 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   float4 shc = make_float4(0, 0, 0, 0);
   float best_t = 0.f, best_u = 0.f, best_v = 0.f;
   int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
-  const BvhNodeQ* nodes = a.sc.tlas_nodes;
+  const char* const node_bytes = reinterpret_cast<const char*>(a.sc.blas_nodes);   // BLAS nodes, then the TLAS nodes
 
   auto push = [&](int v) {
-    if (sp < STACK2_LDS) stk[sp * 64] = v; else ovf[sp - STACK2_LDS] = v;
+    if (sp < STACK2_LDS) stk[sp * 64] = v;
+    else *reinterpret_cast<volatile int32_t*>(ovf + (sp - STACK2_LDS)) = v;
     sp++;
   };
   auto pop = [&]() {
     sp--;
-    if (sp < STACK2_LDS) cur = stk[sp * 64]; else cur = ovf[sp - STACK2_LDS];
+    if (sp < STACK2_LDS) cur = stk[sp * 64];
+    else cur = *reinterpret_cast<volatile int32_t*>(ovf + (sp - STACK2_LDS));   // volatile: never merged with the LDS load into a flat_load
   };
 
   for (;;) {
@@ -399,9 +415,9 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
           co = wo; cd = wd;
           quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
           best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
-          cur_inst = -1; nodes = a.sc.tlas_nodes;
+          cur_inst = -1;
           stk[0] = REF_DONE; sp = 1;
-          cur = 0;   // TLAS root (always interior)
+          cur = a.sc.tlas_root;   // TLAS root (always interior)
           need = false;
         }
         chunk_pos += n_need < avail ? n_need : avail;
@@ -412,12 +428,12 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
 
     // ---- (B) interior-node loop: runs while most live lanes are at interior nodes
     for (;;) {
-      const bool interior = !need && cur >= 0;
+      const bool interior = cur >= 0;   // idle lanes hold REF_DONE
       const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(interior));
       if (n_int == 0 || n_int < keep_going) break;
       if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
       if (interior) {
-        const uint4* np = reinterpret_cast<const uint4*>(nodes + cur);   // 32-byte node: two requests
+        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
         const uint4 Q0 = np[0], Q1 = np[1];
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
@@ -434,48 +450,50 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
       }
     }
 
-    // ---- (C) the rarer bodies, each run once for all lanes that wait at them
-    if (!need && cur < 0 && cur != REF_DONE) {
-      if (cur == REF_MARK) {
-        // leave the instance: back to the world-space ray and the TLAS
-        co = wo; cd = wd;
-        quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
-        nodes = a.sc.tlas_nodes; cur_inst = -1;
-        pop();
-      } else if (cur_inst < 0) {
-        // TLAS leaf: enter the instance (ray -> object space, t preserved)
-        const int ii = ~cur;
-        const InstanceDev* I = a.sc.inst + ii;
-        if ((I->mask & 0xFFu) == 0u) pop();
-        else {
-          float m[12];
-          const float4* mp = reinterpret_cast<const float4*>(I->w2o);
-          float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-          m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
-          m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
-          co = xform_point(m, wo); cd = xform_vec(m, wd);
-          quant_space(co, cd, I->q_lo, I->q_scale, qs, qb);
-          push(REF_MARK);
-          cur_inst = ii; nodes = a.sc.blas_nodes; cur = I->blas_root;
+    // ---- (C) the rarer bodies, each run once for all lanes that wait at them.  They are chained (leaf, then
+    // leave-instance, then enter-instance) so that a lane can finish a leaf, leave its instance and enter the
+    // next one in the same pass instead of waiting a whole pass for each step.
+    if (cur < 0 && cur > REF_MARK && cur_inst >= 0) {
+      // BLAS leaf: Moller-Trumbore on 48-byte packets
+      const uint32_t ref = (uint32_t)(~cur);
+      const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+      for (uint32_t k = 0; k < count; k++) {
+        const float4* tp = a.sc.tris + (size_t)(first + k) * 3;
+        const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+        if (COUNT) cnt_tris++;
+        float tt, uu, vv;
+        if (tri_test(T0, T1, T2, co, cd, tmin, tmax, tt, uu, vv)) {
+          const int prim = (int)__float_as_uint(T2.y);
+          const bool better = (best_inst < 0) || (tt < best_t) ||
+                              (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
+          if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
         }
-      } else {
-        // BLAS leaf: Moller-Trumbore on 48-byte packets
-        const uint32_t ref = (uint32_t)(~cur);
-        const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
-        for (uint32_t k = 0; k < count; k++) {
-          const float4* tp = a.sc.tris + (size_t)(first + k) * 3;
-          const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
-          if (COUNT) cnt_tris++;
-          float tt, uu, vv;
-          if (tri_test(T0, T1, T2, co, cd, tmin, tmax, tt, uu, vv)) {
-            const int prim = (int)__float_as_uint(T2.y);
-            const bool better = (best_inst < 0) || (tt < best_t) ||
-                                (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
-            if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
-          }
-        }
-        if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
-        else pop();
+      }
+      if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
+      else pop();
+    }
+    if (cur == REF_MARK) {
+      // leave the instance: back to the world-space ray and the TLAS
+      co = wo; cd = wd;
+      quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
+      cur_inst = -1;
+      pop();
+    }
+    if (cur < 0 && cur > REF_MARK && cur_inst < 0) {
+      // TLAS leaf: enter the instance (ray -> object space, t preserved)
+      const int ii = ~cur;
+      const InstanceDev* I = a.sc.inst + ii;
+      if ((I->mask & 0xFFu) == 0u) pop();
+      else {
+        float m[12];
+        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
+        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
+        co = xform_point(m, wo); cd = xform_vec(m, wd);
+        quant_space(co, cd, I->q_lo, I->q_scale, qs, qb);
+        push(REF_MARK);
+        cur_inst = ii; cur = I->blas_root;
       }
     }
 
@@ -975,11 +993,14 @@ static TraceArgs make_args(const SceneDev& sc, uint32_t* counters, int queue, ui
   a.work = counters + cnt_work(queue, 0);
   a.shard_cap = shard_cap;
   a.ovf_stack = ovf;
+  a.rays_per_lane = 4; a.min_blocks = 8;
   return a;
 }
 
 template <int MODE, bool ANY>
-static void launch_trace(const TraceArgs& a, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+  TraceArgs a = a_in;
+  a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
   const dim3 g(cfg.trace_blocks), b(256);
   if (cfg.variant == 0) {
     if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true>), g, b, 0, s, a);

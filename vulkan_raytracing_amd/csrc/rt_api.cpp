@@ -75,9 +75,10 @@ struct rt_ctx {
   Bvh4 tlas4;
   bool tlas_valid = false;
   InstanceDev* d_inst = nullptr;
-  BvhNodeQ* d_tlas_nodes = nullptr;
+  std::vector<BvhNodeQ> h_blasq;    // host copy of the linked BLAS nodes (re-uploaded when the array grows)
+  size_t cap_nodesq = 0;
   float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
-  size_t cap_inst = 0, cap_tlas_nodes = 0;
+  size_t cap_inst = 0;
 
   // uniforms (binding 1), cube map (binding 5)
   UniformsDev uni{};
@@ -194,13 +195,12 @@ int link_blas(rt_ctx* c) {
     }
     if (!m.tris.empty()) memcpy(&tris[m.tri_base], m.tris.data(), m.tris.size() * sizeof(TriPacket));
   }
-  if (c->d_blas_nodes) { HIP_TRY(c, hipFree(c->d_blas_nodes)); c->d_blas_nodes = nullptr; }
+  if (c->d_blas_nodes) { HIP_TRY(c, hipFree(c->d_blas_nodes)); c->d_blas_nodes = nullptr; c->cap_nodesq = 0; }
   if (c->d_tris) { HIP_TRY(c, hipFree(c->d_tris)); c->d_tris = nullptr; }
   if (c->d_nodes4) { HIP_TRY(c, hipFree(c->d_nodes4)); c->d_nodes4 = nullptr; c->cap_nodes4 = 0; }
   c->h_blas4.swap(nodes4); c->n_blas4 = nn4;
-  HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, std::max<size_t>(1, nn) * sizeof(BvhNodeQ)));
   HIP_TRY(c, hipMalloc((void**)&c->d_tris, std::max<size_t>(1, nt) * sizeof(TriPacket)));
-  if (nn) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, nodes.data(), nn * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
+  c->h_blasq.swap(nodes);
   if (nt) HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriPacket), hipMemcpyHostToDevice));
   c->n_blas_nodes = nn; c->n_tris = nt;
   c->blas_linked = true;
@@ -214,10 +214,12 @@ int upload_instances(rt_ctx* c) {
     HIP_TRY(c, hipMalloc((void**)&c->d_inst, n * sizeof(InstanceDev)));
     c->cap_inst = n;
   }
-  if (c->tlas.nodes.size() > c->cap_tlas_nodes) {
-    if (c->d_tlas_nodes) HIP_TRY(c, hipFree(c->d_tlas_nodes));
-    HIP_TRY(c, hipMalloc((void**)&c->d_tlas_nodes, c->tlas.nodes.size() * sizeof(BvhNodeQ)));
-    c->cap_tlas_nodes = c->tlas.nodes.size();
+  const size_t needq = c->n_blas_nodes + c->tlas.nodes.size();
+  if (needq > c->cap_nodesq || !c->d_blas_nodes) {
+    if (c->d_blas_nodes) HIP_TRY(c, hipFree(c->d_blas_nodes));
+    c->cap_nodesq = needq + 64;
+    HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, c->cap_nodesq * sizeof(BvhNodeQ)));
+    if (c->n_blas_nodes) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, c->h_blasq.data(), c->n_blas_nodes * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
   }
   // stream-ordered so a per-frame update never stalls the host on a fence (the reference blocks on
   // vkWaitForFences every frame, src/main.cpp:772-778)
@@ -237,7 +239,11 @@ int upload_instances(rt_ctx* c) {
   HIP_TRY(c, hipMemcpyAsync(c->d_nodes4 + c->n_blas4, t4.data(), t4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, c->stream));
   std::vector<BvhNodeQ> tq;
   quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
-  HIP_TRY(c, hipMemcpyAsync(c->d_tlas_nodes, tq.data(), tq.size() * sizeof(BvhNodeQ), hipMemcpyHostToDevice, c->stream));
+  for (auto& nd : tq) {   // interior links are relative to the TLAS: rebase them behind the BLAS nodes
+    if (nd.child0 >= 0) nd.child0 += (int32_t)c->n_blas_nodes;
+    if (nd.child1 >= 0) nd.child1 += (int32_t)c->n_blas_nodes;
+  }
+  HIP_TRY(c, hipMemcpyAsync(c->d_blas_nodes + c->n_blas_nodes, tq.data(), tq.size() * sizeof(BvhNodeQ), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rewritten by the next call
   return RT_OK;
 }
@@ -245,7 +251,7 @@ int upload_instances(rt_ctx* c) {
 SceneDev scene_dev(const rt_ctx* c) {
   SceneDev s{};
   s.nodes4 = c->d_nodes4; s.tlas_root4 = (int)c->n_blas4;
-  s.blas_nodes = c->d_blas_nodes; s.tris = c->d_tris; s.tlas_nodes = c->d_tlas_nodes; s.inst = c->d_inst;
+  s.blas_nodes = c->d_blas_nodes; s.tlas_root = (int)c->n_blas_nodes; s.tris = c->d_tris; s.inst = c->d_inst;
   s.verts = c->d_verts; s.idx = c->d_idx; s.sky = c->d_sky; s.n_inst = (int)c->h_inst_dev.size();
   s.sky_w = c->sky_w; s.sky_h = c->sky_h;
   for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
@@ -409,6 +415,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   // persistent grids: ~27 KB of LDS and <= 84 VGPRs per 256-thread block admit 5-6 blocks per CU
   c->cfg.trace_blocks = c->n_cu * 6;
   c->cfg.shade_blocks = c->n_cu * 8;
+  c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
   if (const char* env = getenv("RT_TRACE_VARIANT")) c->cfg.variant = atoi(env) ? 1 : 0;
@@ -422,7 +429,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_tlas_nodes, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
+  void* ptrs[] = {c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -553,6 +560,8 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     if (c->d_ovf && value * c->n_cu > c->cfg.trace_blocks) { hipFree(c->d_ovf); c->d_ovf = nullptr; }
     c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
   }
+  if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
+  if (k == "trace_min_blocks") { if (value < 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_min_blocks must be >= 8"); c->cfg.min_blocks = value; return RT_OK; }
   if (k == "shade_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "shade_blocks_per_cu must be 1..16"); c->cfg.shade_blocks = c->n_cu * value; return RT_OK; }
   return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown parameter " + k);
 }

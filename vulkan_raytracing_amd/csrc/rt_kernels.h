@@ -8,9 +8,9 @@
 namespace rt {
 
 struct SceneDev {
-  const BvhNodeQ* blas_nodes;  // variant 0: quantized BVH2 nodes of all meshes
+  const BvhNodeQ* blas_nodes;  // variant 0: quantized BVH2 nodes of all meshes, then the quantized TLAS nodes
+  int tlas_root;               // index of the TLAS root in blas_nodes
   const float4* tris;          // 3 float4 per TriPacket
-  const BvhNodeQ* tlas_nodes;  // variant 0: quantized TLAS nodes
   float tlas_q_lo[3], tlas_q_scale[3];
   const Bvh4Node* nodes4;      // quad traversal (variant 1): BLAS BVH4 nodes, then the TLAS BVH4 nodes
   int tlas_root4;              // index of the TLAS root in nodes4
@@ -43,6 +43,8 @@ struct FrameDev {
 struct LaunchCfg {
   int trace_blocks;            // persistent grid of the traversal kernels (256 threads each)
   int shade_blocks;
+  int rays_per_lane;           // device-side grid sizing of the traversal kernels (see k_trace)
+  int min_blocks;
   int variant;                 // 0: BVH2, one lane per ray; 1: BVH4, four lanes per ray (default)
 };
 
