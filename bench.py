@@ -170,12 +170,13 @@ def main():
     for _ in range(args.warmup):
         step()
     sync()
+    ctx.stats()             # drop the warm-up frames' event times
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     sync()
     dt = time.perf_counter() - t0
-    st = ctx.stats()        # counters + event times of context 0's LAST timed frame (all frames are identical)
+    st = ctx.stats()        # counters of context 0's last frame + MEAN event times over all its timed frames (every P-th step)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_secondary, st.rays_shadow], dtype=torch.float64, device=dev)
     if n > 1:
@@ -222,8 +223,8 @@ def main():
                               "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore",
                               "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
                               "algorithmic_bytes_per_launch": alg_bytes / launches,
-                              "timing": "HIP events on the kernel's own stream, live in the timed region (context 0's last frame); with %d frames in flight the kernel "
-                                        "shares the GPU with the kernels of the other frames, so its launch duration is longer than when it runs alone" % P,
+                              "timing": "HIP events on the kernel's own stream, live in the timed region: mean over context 0's %d timed frames (every %d-th step); with %d frames "
+                                        "in flight the kernel shares the GPU with the kernels of the other frames, so a launch lasts longer than when it runs alone" % (st.timed_frames, P, P),
                               "isolated": {"achieved": achieved_iso, "frac": achieved_iso / HBM_PEAK_GBS, "avg_launch_ms": iso_ms / launches,
                                            "timing": "median of 5 frames run one at a time right after the timed region (same process, same buffers)"},
                               "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,

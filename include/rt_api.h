@@ -96,8 +96,11 @@ typedef struct rt_stats {
   float ms_trace_shadow;     /* any-hit traversal kernel */
   float ms_shade;
   float ms_resolve;
-  uint32_t launches_trace_closest;
+  uint32_t launches_trace_closest;   /* per frame */
   uint32_t launches_total;
+  uint32_t timed_frames;     /* the ms_* fields are means over this many frames (all frames enqueued with timing on
+                                since the previous rt_get_stats / rt_trace) */
+  uint32_t reserved;
   uint32_t bvh_node_bytes;   /* S_node, S_tri of the roofline formula */
   uint32_t bvh_tri_bytes;
 } rt_stats;

@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+BENCH="python3 bench.py --no-cpu-baseline"   # the default command (60 steps, 3 frames in flight), minus the CPU leg
 # 1) per-kernel time
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "kernel-trace failed"; tail -5 $OUT/trace.log; exit 1; }
 # 2) PMC passes (own runs, no tracing domains besides kernel-trace): FETCH_SIZE and WRITE_SIZE separately

@@ -99,6 +99,7 @@ struct rt_ctx {
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
   std::vector<TimedSpan> spans;
+  uint32_t timed_frames = 0;     // frames whose spans are waiting in `spans` (averaged by rt_get_stats)
   rt_stats last{};
   bool frame_pending = false;
   hipStream_t frame_stream = nullptr;
@@ -320,7 +321,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   const SceneDev sc = scene_dev(c);
-  c->ev_used = 0; c->spans.clear();
+  // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
+  // pool is recycled every 64 frames
+  if (!c->timing || c->timed_frames >= 64) { c->ev_used = 0; c->spans.clear(); c->timed_frames = 0; }
+  if (c->timing) c->timed_frames++;
   c->frame_stream = s; c->frame_pending = true;
   c->last_max_bounce = u.max_bounce_count;
   c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
@@ -382,6 +386,13 @@ int collect_stats(rt_ctx* c) {
     }
     if (sp.cat != CAT_FRAME) st.launches_total++;
   }
+  if (c->timed_frames > 1) {   // mean per frame over every frame recorded since the last read
+    const float k = 1.0f / (float)c->timed_frames;
+    st.ms_raygen *= k; st.ms_trace_closest *= k; st.ms_shade *= k; st.ms_trace_shadow *= k; st.ms_resolve *= k; st.ms_frame *= k;
+    st.launches_trace_closest /= c->timed_frames; st.launches_total /= c->timed_frames;
+  }
+  st.timed_frames = c->timed_frames;
+  c->ev_used = 0; c->spans.clear(); c->timed_frames = 0;
   c->last = st;
   c->frame_pending = false;
   return RT_OK;
