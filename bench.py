@@ -94,6 +94,9 @@ def main():
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
     ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
+                         "reassembly where only one GPU exists (its throughput is meaningless)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,8 +106,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the ray-tracing stage has no CPU path")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group(backend="gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
         local_rank = 0
@@ -151,7 +159,14 @@ def main():
         counter[0] += 1
         with torch.cuda.stream(streams[j]):
             ctxs[j].trace_shard(WIDTH, HEIGHT, band, rank, n, shards[j].data_ptr(), shards[j].numel() * 4, streams[j].cuda_stream)
-            if n > 1:
+            if n > 1 and args.rehearse_on_one_gpu:
+                streams[j].synchronize()
+                host_shard = shards[j].cpu()
+                parts = [torch.zeros_like(host_shard) for _ in range(n)] if rank == 0 else None
+                dist.gather(host_shard, parts, dst=0)
+                if rank == 0:
+                    frames[j] = torch.cat(parts).index_select(0, perm.cpu()).to(dev)
+            elif n > 1:
                 dist.gather(shards[j], list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
                 if rank == 0:
                     frames[j] = gathered[j].view(n * rows_max, WIDTH, 4).index_select(0, perm)
@@ -238,8 +253,9 @@ def main():
                 result["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
             except Exception:
                 pass
-        if args.save_image and frames[0] is not None:
-            img = frames[0][:HEIGHT].cpu().numpy()
+        last = (counter[0] - 1) % P
+        if args.save_image and frames[last] is not None:
+            img = frames[last][:HEIGHT].cpu().numpy()
             with open(args.save_image, "wb") as fh:
                 fh.write(b"PF4\n%d %d\n-1.0\n" % (WIDTH, HEIGHT))
                 fh.write(img[::-1].astype("<f4").tobytes())

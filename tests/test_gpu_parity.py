@@ -234,3 +234,21 @@ def test_trace_variants_are_result_identical(ctx):
     o = sp.orc.intersect(rays, use_bvh=True)
     same = (out[1][0]["prim"] == o["prim"]) & (out[1][0]["inst"] == o["inst"]) & (out[1][0]["t"].view(np.uint32) == o["t"].view(np.uint32))
     assert same.mean() >= 0.9999
+
+
+def test_bench_two_ranks_on_one_gpu_reassemble_the_same_frame(tmp_path):
+    """bench.py's N > 1 path (rank -> bands, gather, row permutation) rehearsed with two ranks sharing the one GPU
+    over gloo: the gathered 1920x1080 frame equals the single-rank frame bit for bit."""
+    import subprocess
+    import sys
+    a, b = str(tmp_path / "one.pfm"), str(tmp_path / "two.pfm")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--save-image", a],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--rehearse-on-one-gpu", "--save-image", b], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    fa, fb = open(a, "rb").read(), open(b, "rb").read()
+    assert len(fa) == len(fb) and fa == fb
