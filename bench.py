@@ -97,7 +97,14 @@ def main():
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
                          "reassembly where only one GPU exists (its throughput is meaningless)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: still create the RCCL process group and run the per-frame gather (to itself) — a smoke test of the N > 1 code path")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: library banners (RCCL prints its version to fd 1) go to stderr
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -116,15 +123,20 @@ def main():
     else:
         torch.cuda.set_device(0)
         local_rank = 0
+        if args.force_collective:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     dev = torch.device("cuda", local_rank)
     n = world
+    collective = n > 1 or args.force_collective
     assert args.gpus == n, "--gpus must equal the number of launched ranks"
     P = max(1, args.frames_in_flight)
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
         host.armadillo_path(res)  # generate the stand-in once before the other ranks look for it
-    if n > 1:
+    if collective:
         dist.barrier()
     # one context (scene replica, queues, counters) per frame in flight — the analogue of the reference's
     # per-swapchain-image command buffer, fence and semaphores (src/main.cpp:2597, 2740-2749)
@@ -142,9 +154,9 @@ def main():
     band = tiling.BAND_ROWS
     rows_max = tiling.max_shard_rows(HEIGHT, band, n)
     shards = [torch.zeros((rows_max, WIDTH, 4), dtype=torch.float32, device=dev) for _ in range(P)]
-    gathered = [torch.zeros((n, rows_max, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and n > 1) else None for _ in range(P)]
+    gathered = [torch.zeros((n, rows_max, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
     perm = None
-    if rank == 0 and n > 1:
+    if rank == 0 and collective:
         src = np.zeros(HEIGHT, np.int64)
         for s in range(n):
             m = tiling.shard_row_map(HEIGHT, band, s, n)
@@ -166,7 +178,7 @@ def main():
                 dist.gather(host_shard, parts, dst=0)
                 if rank == 0:
                     frames[j] = torch.cat(parts).index_select(0, perm.cpu()).to(dev)
-            elif n > 1:
+            elif collective:
                 dist.gather(shards[j], list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
                 if rank == 0:
                     frames[j] = gathered[j].view(n * rows_max, WIDTH, 4).index_select(0, perm)
@@ -177,7 +189,7 @@ def main():
         for s_ in streams:
             s_.synchronize()
         torch.cuda.synchronize(dev)
-        if n > 1:
+        if collective:
             dist.barrier()
             torch.cuda.synchronize(dev)
 
@@ -194,7 +206,7 @@ def main():
     st = ctx.stats()        # counters of context 0's last frame + MEAN event times over all its timed frames (every P-th step)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_secondary, st.rays_shadow], dtype=torch.float64, device=dev)
-    if n > 1:
+    if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     dt = float(t.item())
@@ -263,8 +275,11 @@ def main():
             result["cpu_baseline"] = cpu_baseline(geom, inst, u, sky)
         else:
             result["cpu_baseline"] = None
-        print(json.dumps(result))
-    if n > 1:
+        sys.stdout.flush()
+        os.dup2(saved_stdout, 1)
+        print(json.dumps(result), flush=True)
+        os.dup2(2, 1)
+    if collective:
         dist.barrier()
         dist.destroy_process_group()
     for c in ctxs:

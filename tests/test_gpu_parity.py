@@ -252,3 +252,17 @@ def test_bench_two_ranks_on_one_gpu_reassemble_the_same_frame(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     fa, fb = open(a, "rb").read(), open(b, "rb").read()
     assert len(fa) == len(fb) and fa == fb
+
+
+def test_bench_rccl_gather_path_single_rank(tmp_path):
+    """The real RCCL code path of bench.py (process group on nccl, per-frame gather on the frame's stream, row
+    permutation) with a world of one rank: must run and reproduce the plain frame."""
+    import subprocess
+    import sys
+    a, b = str(tmp_path / "plain.pfm"), str(tmp_path / "coll.pfm")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    for extra, out in (([], a), (["--force-collective"], b)):
+        r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--save-image", out] + extra,
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+    assert open(a, "rb").read() == open(b, "rb").read()
