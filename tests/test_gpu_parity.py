@@ -266,3 +266,43 @@ def test_bench_rccl_gather_path_single_rank(tmp_path):
                            env=env, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-2000:]
     assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_headless_cpp_host_matches_python_path(tmp_path):
+    """host/rt_headless.cpp (the reference's main() restated in C++ on the C ABI: ingest, BLAS/TLAS, per-frame
+    animate -> TLAS refit -> uniforms -> trace, PFM output) renders the same frame as the ctypes path."""
+    import subprocess
+    exe = os.path.join(scenes.ROOT, "rt_headless")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", scenes.ROOT, "rt_headless"])
+    out = str(tmp_path / "frame")
+    W, H, frames, dt = 200, 120, 3, 0.5
+    r = subprocess.run([exe, "--width", str(W), "--height", str(H), "--frames", str(frames), "--dt", str(dt), "--bounce", "3", "--spp", "2",
+                        "--center", os.path.join(RES, "teapot.obj"), "--orbiting", os.path.join(RES, "cube.obj"),
+                        "--skybox", os.path.join(RES, "skybox_texture_test"), "--out", out], cwd=scenes.ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-1000:]
+    assert "Mrays/s" in r.stdout
+    sys_path = os.path.join(scenes.ROOT, "tools")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("image_diff", os.path.join(sys_path, "image_diff.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    cpp = mod.read_image(out + ".pfm")
+    # the same frame through Python: same scene, same fixed-step animation (timeParam += dt*0.1 per frame)
+    ctx = RtContext(0)
+    geom = host.SceneGeometry([os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj")])
+    ctx.upload_geometry(geom.verts, geom.idx, geom.ranges)
+    anim = host.SceneAnimation()
+    ctx.set_instances(anim.instances((0, 1)))
+    ctx.set_uniforms(host.default_uniforms(max_bounce_count=3, samples_per_pixel=2, orbiting_object_primitive_offset=geom.orbiting_primitive_offset,
+                                           orbiting_object_vertex_offset=geom.orbiting_vertex_offset))
+    ctx.set_skybox(host.load_skybox(os.path.join(RES, "skybox_texture_test")))
+    tp = np.float32(0.0)
+    for _ in range(frames):
+        tp = np.float32(tp + np.float32(dt) * np.float32(0.1))
+        anim.animate(float(tp))
+        ctx.set_instances(anim.instances((0, 1)), update=True)
+    img, _ = ctx.trace(W, H)
+    ctx.close()
+    assert np.array_equal(cpp, img[..., :3])
+    ppm = mod.read_image(out + ".ppm")
+    assert np.abs(ppm - np.clip(img[..., :3], 0, 1)).max() <= 0.5 / 255 + 1e-6

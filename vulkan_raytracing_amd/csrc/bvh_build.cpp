@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace rt {
@@ -42,6 +43,7 @@ inline int levels_needed(uint32_t n, int max_leaf) {
 struct Builder {
   std::vector<Ref> refs;
   int max_leaf, max_depth;
+  float trav_cost = 1.0f;   // SAH: cost of visiting an interior node relative to one triangle test
   BuiltBvh* out;
 
   int build(uint32_t first, uint32_t count, int depth) {
@@ -87,7 +89,7 @@ struct Builder {
     float pa = half_area(bounds);
     if (count <= (uint32_t)max_leaf) {
       float leaf_cost = pa * (float)count;
-      float split_cost = best_axis >= 0 ? pa * 1.0f + best_cost : BIG;
+      float split_cost = best_axis >= 0 ? pa * trav_cost + best_cost : BIG;
       if (leaf_cost <= split_cost) { out->topo[me].count = count; out->leaves++; return me; }
     }
     uint32_t mid = first;
@@ -154,13 +156,14 @@ struct Emitter {
 
 }  // namespace
 
-static void build_bvh_impl(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, bool direct_ids, BuiltBvh& out) {
+static void build_bvh_impl(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, bool direct_ids, BuiltBvh& out, float trav_cost = 1.0f) {
   out = BuiltBvh{};
   box_reset(out.bounds);
   Builder b;
   b.max_leaf = std::max(1, std::min(8, max_leaf));
   b.max_depth = std::max(max_depth, levels_needed(std::max(1u, n), b.max_leaf) + 1);
   b.out = &out;
+  b.trav_cost = trav_cost;
   b.refs.resize(n);
   for (uint32_t i = 0; i < n; i++) {
     b.refs[i].box = prim_boxes[i]; b.refs[i].id = i;
@@ -353,7 +356,11 @@ void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, Buil
     }
     boxes[p] = b;
   }
-  build_bvh_impl(boxes.data(), n_prims, 4, BLAS_MAX_DEPTH, false, bvh);
+  // experiment knobs (defaults are the measured best): RT_BVH_MAX_LEAF 1..8, RT_BVH_TRAV_COST
+  int max_leaf = 4; float trav_cost = 1.0f;
+  if (const char* e = getenv("RT_BVH_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 8) max_leaf = v; }
+  if (const char* e = getenv("RT_BVH_TRAV_COST")) { float v = (float)atof(e); if (v > 0.f) trav_cost = v; }
+  build_bvh_impl(boxes.data(), n_prims, max_leaf, BLAS_MAX_DEPTH, false, bvh, trav_cost);
   tris.resize(n_prims);
   for (uint32_t i = 0; i < n_prims; i++) {
     uint32_t p = bvh.order[i];
