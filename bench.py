@@ -154,7 +154,10 @@ def main():
     band = tiling.BAND_ROWS
     rows_max = tiling.max_shard_rows(HEIGHT, band, n)
     shards = [torch.zeros((rows_max, WIDTH, 4), dtype=torch.float32, device=dev) for _ in range(P)]
-    gathered = [torch.zeros((n, rows_max, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
+    # the gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183),
+    # so 25 % of the xGMI traffic into rank 0 would be constants
+    gathered = [torch.zeros((n, rows_max, WIDTH, 3), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
+    full = [torch.ones((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
     perm = None
     if rank == 0 and collective:
         src = np.zeros(HEIGHT, np.int64)
@@ -179,9 +182,11 @@ def main():
                 if rank == 0:
                     frames[j] = torch.cat(parts).index_select(0, perm.cpu()).to(dev)
             elif collective:
-                dist.gather(shards[j], list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
+                rgb = shards[j][..., :3].contiguous()
+                dist.gather(rgb, list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
                 if rank == 0:
-                    frames[j] = gathered[j].view(n * rows_max, WIDTH, 4).index_select(0, perm)
+                    full[j][..., :3] = gathered[j].view(n * rows_max, WIDTH, 3).index_select(0, perm)
+                    frames[j] = full[j]
             else:
                 frames[j] = shards[j]
 
