@@ -29,9 +29,25 @@ import torch.distributed as dist  # noqa: E402
 
 from vulkan_raytracing_amd import RtContext, host, tiling  # noqa: E402
 
-WIDTH, HEIGHT, MAX_BOUNCE, SPP = 1920, 1080, 3, 4
+WIDTH, HEIGHT, MAX_BOUNCE, SPP = 1920, 1080, 3, 4   # BASELINE config 3 (the headline); --workload cfg4 / cfg5 change them
+WORKLOAD = "cfg3"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
 RAY_BYTES, HIT_BYTES = 32, 20
+
+
+def ring_instances(n_inst, radius):
+    """cfg5: n instances of the orbiting mesh's BLAS on a ring about the origin (generalises M1 = T(0,0,5) of
+    src/main.cpp:1805-1808), all with customIndex 1, plus the center mesh as instance 0."""
+    from vulkan_raytracing_amd.api import INSTANCE_DTYPE
+    inst = np.zeros(n_inst + 1, INSTANCE_DTYPE)
+    inst[0] = host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)
+    for k in range(n_inst):
+        a = 2.0 * np.pi * k / n_inst
+        c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
+        # R_y(a) * T(0,0,radius): rotation then the translated offset
+        t = np.array([c, 0, s, s * radius, 0, 1, 0, 0, -s, 0, c, c * radius], np.float32)
+        inst[k + 1] = host.make_instance(t, 1, 1)
+    return inst
 
 
 def build_scene(ctx, res):
@@ -39,7 +55,7 @@ def build_scene(ctx, res):
     geom = host.SceneGeometry([os.path.join(res, "teapot.obj"), arm])
     ctx.upload_geometry(geom.verts, geom.idx, geom.ranges)
     anim = host.SceneAnimation()                      # t = 0: M0 = I, M1 = T(0,0,5) (src/main.cpp:1805-1808)
-    inst = anim.instances((0, 1))
+    inst = ring_instances(16, 10.0) if WORKLOAD == "cfg5" else anim.instances((0, 1))
     ctx.set_instances(inst)
     u = host.default_uniforms(max_bounce_count=MAX_BOUNCE, samples_per_pixel=SPP, center_object_type=1, orbiting_object_type=0,
                               orbiting_object_primitive_offset=geom.orbiting_primitive_offset,
@@ -94,12 +110,18 @@ def main():
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
     ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
+                    help="cfg3 (default, the headline): 1920x1080 depth 4; cfg4: 3840x2160 depth 6; cfg5: 16 instances of the armadillo BLAS, 1920x1080 depth 4")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
                          "reassembly where only one GPU exists (its throughput is meaningless)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank: still create the RCCL process group and run the per-frame gather (to itself) — a smoke test of the N > 1 code path")
     args = ap.parse_args()
+    global WIDTH, HEIGHT, MAX_BOUNCE, WORKLOAD
+    WORKLOAD = args.workload
+    if WORKLOAD == "cfg4":
+        WIDTH, HEIGHT, MAX_BOUNCE = 3840, 2160, 5
 
     # stdout carries exactly one JSON line: library banners (RCCL prints its version to fd 1) go to stderr
     sys.stdout.flush()
@@ -222,11 +244,11 @@ def main():
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total_rays * args.steps / dt / 1e6
-        result = {"metric": "Mrays/sec (primary+secondary+shadow) at 1920x1080 depth 4", "value": value, "unit": "Mrays/s",
+        result = {"metric": "Mrays/sec (primary+secondary+shadow) at %dx%d depth %d" % (WIDTH, HEIGHT, MAX_BOUNCE + 1), "value": value, "unit": "Mrays/s",
                   "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": "BASELINE cfg3: teapot.obj mirror + %s diffuse, skybox_texture_sea, %dx%d, maxBounceCount %d (depth 4) + shadow rays, spp %d"
-                                         % (arm_label, WIDTH, HEIGHT, MAX_BOUNCE, SPP),
+                  "config": {"workload": "BASELINE %s: teapot.obj mirror + %s diffuse%s, skybox_texture_sea, %dx%d, maxBounceCount %d (depth %d) + shadow rays, spp %d"
+                                         % (WORKLOAD, arm_label, " x16 instances on a ring (one BLAS, two-level BVH)" if WORKLOAD == "cfg5" else "", WIDTH, HEIGHT, MAX_BOUNCE, MAX_BOUNCE + 1, SPP),
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
                              "parallelism": "interleaved %d-row bands over %d GPU(s), scene replicated, one RCCL gather per frame, %d frames in flight per GPU" % (band, n, P),
                              "frames_in_flight": P, "device": ctx.device_info}}
