@@ -11,8 +11,8 @@ HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vec
 
 all: $(PKG)/librt_mi355x.so oracle
 
-$(PKG)/librt_mi355x.so: $(CSRC)/kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/bvh_build.h include/rt_api.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp
+$(PKG)/librt_mi355x.so: $(CSRC)/kernels.hip $(CSRC)/bvh_gpu.hip $(CSRC)/bvh_gpu.h $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/bvh_build.h include/rt_api.h
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/bvh_gpu.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp
 
 oracle:
 	$(MAKE) -C oracle all
@@ -36,4 +36,4 @@ rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/jpeg
 
 # kernel experiments: make exp EXP_NAME=<suffix> EXP_FLAGS="-DRT_EXP_..."  -> librt_mi355x_<suffix>.so (load with RT_LIB_VARIANT)
 exp:
-	$(HIPCC) $(HIPFLAGS) $(EXP_FLAGS) -shared -o $(PKG)/librt_mi355x_$(EXP_NAME).so $(CSRC)/kernels.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp
+	$(HIPCC) $(HIPFLAGS) $(EXP_FLAGS) -shared -o $(PKG)/librt_mi355x_$(EXP_NAME).so $(CSRC)/kernels.hip $(CSRC)/bvh_gpu.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp

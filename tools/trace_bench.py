@@ -23,12 +23,17 @@ def main():
     ap.add_argument("--center-type", type=int, default=1)
     ap.add_argument("--variants", default="0,1")
     ap.add_argument("--blocks", default="4,6,8")
+    ap.add_argument("--blas-builder", type=int, default=0)
     args = ap.parse_args()
     res = os.path.join(ROOT, "resources")
     ctx = RtContext(0)
     arm, label = host.armadillo_path(res)
     geom = host.SceneGeometry([os.path.join(res, "teapot.obj"), arm])
-    ctx.upload_geometry(geom.verts, geom.idx, geom.ranges)
+    import time
+    ctx.set_param("blas_builder", args.blas_builder)
+    ctx.upload_geometry(geom.verts, geom.idx, geom.ranges, build=False)
+    for m in range(len(geom.ranges)):
+        t0 = time.perf_counter(); ctx.build_blas(m); print(json.dumps({"blas_builder": args.blas_builder, "mesh": m, "triangles": geom.ranges[m][2], "build_ms": round((time.perf_counter() - t0) * 1e3, 2)}), flush=True)
     anim = host.SceneAnimation()
     if args.time_param:
         anim.animate(args.time_param)

@@ -1,0 +1,299 @@
+// bvh_gpu.hip — BLAS build on the GPU (what the driver does behind vkCmdBuildAccelerationStructuresKHR in
+// the reference, src/main.cpp:495-498, with VK_ACCELERATION_STRUCTURE_BUILD_TYPE_DEVICE_KHR, :345-357).
+//
+// Linear BVH: triangle boxes + bounds -> 30-bit Morton codes of the centroids -> radix sort (rocPRIM through
+// hipcub; the sort is plumbing) -> binary radix tree built in parallel, one thread per internal node (Karras,
+// "Maximizing Parallelism in the Construction of BVHs, Octrees, and k-d Trees", HPG 2012) -> bottom-up box
+// propagation with one atomic arrival flag per node -> emit: subtrees of <= max_leaf triangles become leaves (default 1), every
+// surviving internal node is written as a 32-byte quantized BvhNodeQ (rt_device.h), triangles as 48-byte packets
+// in sorted order.  Output indices are local to the mesh (root = node 0); rt_api.cpp rebases them when linking.
+//
+// Any valid BVH yields the same hits (the tie rule makes results independent of traversal order), so images from
+// this builder are bit-identical to those from the host SAH builder — tested in tests/test_gpu_parity.py.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdlib>
+#include <string>
+
+#include "bvh_gpu.h"
+
+namespace rt {
+namespace {
+
+// monotone float <-> uint mapping so that atomicMin/atomicMax on uints order floats
+__device__ __forceinline__ uint32_t f2ord(float f) { uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+
+struct Box { float lo[3], hi[3]; };
+
+__global__ void k_init_bounds(uint32_t* b) {
+  if (threadIdx.x < 3) b[threadIdx.x] = 0xFFFFFFFFu;       // min accumulators
+  else if (threadIdx.x < 6) b[threadIdx.x] = 0u;           // max accumulators
+}
+
+// per triangle: box, centroid bounds (block-reduced, then 6 atomics per block)
+__global__ __launch_bounds__(256) void k_tri_boxes(const float* verts6, const uint32_t* idx, uint32_t n, Box* boxes, uint32_t* cbounds) {
+  __shared__ uint32_t s_b[6];
+  if (threadIdx.x < 3) s_b[threadIdx.x] = 0xFFFFFFFFu; else if (threadIdx.x < 6) s_b[threadIdx.x] = 0u;
+  __syncthreads();
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p < n) {
+    Box b;
+    for (int k = 0; k < 3; k++) { b.lo[k] = 3.0e38f; b.hi[k] = -3.0e38f; }
+    for (int c = 0; c < 3; c++) {
+      const float* v = verts6 + 6ull * idx[3ull * p + c];
+      for (int k = 0; k < 3; k++) { b.lo[k] = fminf(b.lo[k], v[k]); b.hi[k] = fmaxf(b.hi[k], v[k]); }
+    }
+    boxes[p] = b;
+    for (int k = 0; k < 3; k++) {
+      const float cen = 0.5f * b.lo[k] + 0.5f * b.hi[k];
+      atomicMin(&s_b[k], f2ord(cen)); atomicMax(&s_b[3 + k], f2ord(cen));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) atomicMin(&cbounds[threadIdx.x], s_b[threadIdx.x]);
+  else if (threadIdx.x < 6) atomicMax(&cbounds[threadIdx.x], s_b[threadIdx.x]);
+}
+
+__device__ __forceinline__ uint32_t spread3(uint32_t v) {   // 10 bits -> every third bit
+  v = (v * 0x00010001u) & 0xFF0000FFu;
+  v = (v * 0x00000101u) & 0x0F00F00Fu;
+  v = (v * 0x00000011u) & 0xC30C30C3u;
+  v = (v * 0x00000005u) & 0x49249249u;
+  return v;
+}
+
+__global__ __launch_bounds__(256) void k_morton(const Box* boxes, uint32_t n, const uint32_t* cbounds, uint32_t* keys, uint32_t* vals) {
+  const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  uint32_t code = 0;
+  for (int k = 0; k < 3; k++) {
+    const float lo = ord2f(cbounds[k]), hi = ord2f(cbounds[3 + k]);
+    const float ext = hi - lo;
+    const float cen = 0.5f * boxes[p].lo[k] + 0.5f * boxes[p].hi[k];
+    float t = ext > 0.f ? (cen - lo) / ext : 0.f;
+    t = fminf(fmaxf(t * 1024.0f, 0.0f), 1023.0f);
+    code |= spread3((uint32_t)t) << (2 - k);
+  }
+  keys[p] = code; vals[p] = p;
+}
+
+// common-prefix length of sorted keys i and j (ties broken by the index), -1 outside the array
+__device__ __forceinline__ int delta(const uint32_t* keys, int n, int i, int j) {
+  if (j < 0 || j >= n) return -1;
+  const uint32_t a = keys[i], b = keys[j];
+  if (a == b) return 32 + __clz((uint32_t)i ^ (uint32_t)j);
+  return __clz(a ^ b);
+}
+
+// One thread per internal node i in [0, n-1): range, split, children, parents (Karras 2012, algorithm 1).
+// child encoding here: >= 0 internal node, < 0 leaf ~sorted_index
+__global__ __launch_bounds__(256) void k_radix_tree(const uint32_t* keys, int n, int2* children, int2* ranges, int* parent_internal, int* parent_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
+  const int dmin = delta(keys, n, i, i - d);
+  int lmax = 2;
+  while (delta(keys, n, i, i + lmax * d) > dmin) lmax <<= 1;
+  int l = 0;
+  for (int t = lmax >> 1; t >= 1; t >>= 1)
+    if (delta(keys, n, i, i + (l + t) * d) > dmin) l += t;
+  const int j = i + l * d;
+  const int dnode = delta(keys, n, i, j);
+  int s = 0;
+  for (int t = (l + 1) >> 1;; t = (t + 1) >> 1) {
+    if (delta(keys, n, i, i + (s + t) * d) > dnode) s += t;
+    if (t <= 1) break;
+  }
+  const int gamma = i + s * d + min(d, 0);
+  const int lo = min(i, j), hi = max(i, j);
+  const int left = (lo == gamma) ? ~gamma : gamma;
+  const int right = (hi == gamma + 1) ? ~(gamma + 1) : (gamma + 1);
+  children[i] = make_int2(left, right);
+  ranges[i] = make_int2(lo, hi);
+  if (left >= 0) parent_internal[left] = i; else parent_leaf[~left] = i;
+  if (right >= 0) parent_internal[right] = i; else parent_leaf[~right] = i;
+  if (i == 0) parent_internal[0] = -1;
+}
+
+// bottom-up: each leaf climbs; the second arrival at a node merges the children's boxes and continues
+__global__ __launch_bounds__(256) void k_propagate(const Box* tri_boxes, const uint32_t* sorted_ids, int n, const int2* children, const int* parent_internal,
+                                                   const int* parent_leaf, Box* node_boxes, uint32_t* flags) {
+  const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
+  if (leaf >= n) return;
+  int node = parent_leaf[leaf];
+  while (node >= 0) {
+    __threadfence();
+    if (atomicAdd(&flags[node], 1u) == 0u) return;   // first arrival: the sibling subtree is not finished yet
+    __threadfence();
+    const int2 ch = children[node];
+    // (the acquire fence above invalidated this CU's L1, so plain loads see the sibling subtree's boxes)
+    Box a, b;
+    if (ch.x >= 0) a = node_boxes[ch.x]; else a = tri_boxes[sorted_ids[~ch.x]];
+    if (ch.y >= 0) b = node_boxes[ch.y]; else b = tri_boxes[sorted_ids[~ch.y]];
+    Box m;
+    for (int k = 0; k < 3; k++) { m.lo[k] = fminf(a.lo[k], b.lo[k]); m.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+    node_boxes[node] = m;
+    node = parent_internal[node];
+  }
+}
+
+__global__ void k_quant_params(const Box* node_boxes, float* qparams /* lo[3], scale[3], bounds lo[3], hi[3] */) {
+  if (threadIdx.x >= 3) return;
+  const int k = threadIdx.x;
+  const float lo = node_boxes[0].lo[k], hi = node_boxes[0].hi[k];
+  const float ext = hi - lo;
+  const float scale = ext > 0.f ? ext * 1.00001f / 65520.0f : 1e-30f;
+  qparams[k] = lo - 4.0f * scale;       // quanta 0..3 stay below every stored plane
+  qparams[3 + k] = scale;
+  qparams[6 + k] = lo; qparams[9 + k] = hi;
+}
+
+__device__ __forceinline__ uint32_t quant_box_axis(float lo, float hi, float base, float scale) {
+  // two quanta of margin on each side cover the float rounding of the division
+  float ql = floorf((lo - base) / scale) - 2.0f, qh = ceilf((hi - base) / scale) + 2.0f;
+  ql = fminf(fmaxf(ql, 0.0f), 65535.0f); qh = fminf(fmaxf(qh, 0.0f), 65535.0f);
+  return (uint32_t)ql | ((uint32_t)qh << 16);
+}
+
+// emit: internal node i with more than 4 triangles becomes BvhNodeQ[i]; children with <= 4 triangles become leaves
+__global__ __launch_bounds__(256) void k_emit_nodes(const Box* tri_boxes, const uint32_t* sorted_ids, int n, const int2* children, const int2* ranges,
+                                                    const Box* node_boxes, const float* qparams, BvhNodeQ* out, int max_leaf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n - 1) return;
+  const int2 r = ranges[i];
+  BvhNodeQ q{};
+  if (r.y - r.x + 1 > max_leaf) {
+    const int2 ch = children[i];
+    int refs[2]; Box bx[2];
+    const int c[2] = {ch.x, ch.y};
+    for (int k = 0; k < 2; k++) {
+      if (c[k] >= 0) {
+        const int2 cr = ranges[c[k]];
+        const int cnt = cr.y - cr.x + 1;
+        bx[k] = node_boxes[c[k]];
+        refs[k] = cnt <= max_leaf ? ~(int)(((uint32_t)cr.x << 3) | (uint32_t)(cnt - 1)) : c[k];
+      } else {
+        const int leaf = ~c[k];
+        bx[k] = tri_boxes[sorted_ids[leaf]];
+        refs[k] = ~(int)(((uint32_t)leaf << 3) | 0u);
+      }
+    }
+    for (int a = 0; a < 3; a++) {
+      q.w[a] = quant_box_axis(bx[0].lo[a], bx[0].hi[a], qparams[a], qparams[3 + a]);
+      q.w[3 + a] = quant_box_axis(bx[1].lo[a], bx[1].hi[a], qparams[a], qparams[3 + a]);
+    }
+    q.child0 = refs[0]; q.child1 = refs[1];
+  }
+  out[i] = q;
+}
+
+__global__ __launch_bounds__(256) void k_emit_tris(const float* verts6, const uint32_t* idx, const uint32_t* sorted_ids, uint32_t n, float4* out) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t p = sorted_ids[i];
+  const float* v0 = verts6 + 6ull * idx[3ull * p + 0];
+  const float* v1 = verts6 + 6ull * idx[3ull * p + 1];
+  const float* v2 = verts6 + 6ull * idx[3ull * p + 2];
+  // e1 = v1 - v0, e2 = v2 - v0 rounded once in binary32, exactly as the oracle and the host builder do
+  const float e1x = v1[0] - v0[0], e1y = v1[1] - v0[1], e1z = v1[2] - v0[2];
+  const float e2x = v2[0] - v0[0], e2y = v2[1] - v0[1], e2z = v2[2] - v0[2];
+  out[3ull * i + 0] = make_float4(v0[0], v0[1], v0[2], e1x);
+  out[3ull * i + 1] = make_float4(e1y, e1z, e2x, e2y);
+  out[3ull * i + 2] = make_float4(e2z, __uint_as_float(p), 0.f, 0.f);
+}
+
+// copy a mesh's local nodes into the linked array, rebasing interior links and leaf ranges
+__global__ __launch_bounds__(256) void k_rebase_nodes(const BvhNodeQ* src, BvhNodeQ* dst, uint32_t n, int node_base, uint32_t tri_base) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  BvhNodeQ q = src[i];
+  int* ch[2] = {&q.child0, &q.child1};
+  for (int k = 0; k < 2; k++) {
+    const int c = *ch[k];
+    if (c >= 0) *ch[k] = c + node_base;
+    else { const uint32_t ref = (uint32_t)(~c); *ch[k] = ~(int)((((ref >> 3) + tri_base) << 3) | (ref & 7u)); }
+  }
+  dst[i] = q;
+}
+
+#define GB_TRY(expr)                                                                                             \
+  do {                                                                                                           \
+    hipError_t e_ = (expr);                                                                                      \
+    if (e_ != hipSuccess) { err = std::string("HIP runtime exception: return code ") + std::to_string((int)e_) + \
+                                  " (" + hipGetErrorString(e_) + ") in " #expr; cleanup(); return 1; }            \
+  } while (0)
+
+}  // namespace
+
+int build_blas_gpu(const float* d_verts6, const uint32_t* d_idx, uint32_t n, hipStream_t s, GpuBlas& out, std::string& err) {
+  out = GpuBlas{};
+  if (n < 8) { err = "build_blas_gpu needs at least 8 triangles"; return 1; }
+  int max_leaf = 1;   // subtrees of at most this many triangles become leaves (1 measured best: 1.15 ms/frame vs 1.22 at 4)
+  if (const char* e = getenv("RT_LBVH_MAX_LEAF")) { int v = atoi(e); if (v >= 1 && v <= 8) max_leaf = v; }
+  Box *tri_boxes = nullptr, *node_boxes = nullptr;
+  uint32_t *cbounds = nullptr, *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr, *flags = nullptr;
+  int2 *children = nullptr, *ranges = nullptr;
+  int *parent_internal = nullptr, *parent_leaf = nullptr;
+  float* qparams = nullptr;
+  void* tmp = nullptr;
+  auto cleanup = [&]() {
+    for (void* p : {(void*)tri_boxes, (void*)node_boxes, (void*)cbounds, (void*)keys, (void*)keys2, (void*)vals, (void*)vals2, (void*)flags, (void*)children,
+                    (void*)ranges, (void*)parent_internal, (void*)parent_leaf, (void*)qparams, tmp})
+      if (p) hipFree(p);
+  };
+  const uint32_t nb = (n + 255u) / 256u;
+  GB_TRY(hipMalloc((void**)&tri_boxes, n * sizeof(Box)));
+  GB_TRY(hipMalloc((void**)&node_boxes, n * sizeof(Box)));
+  GB_TRY(hipMalloc((void**)&cbounds, 6 * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&keys, n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&keys2, n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&vals, n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&vals2, n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&flags, n * sizeof(uint32_t)));
+  GB_TRY(hipMalloc((void**)&children, n * sizeof(int2)));
+  GB_TRY(hipMalloc((void**)&ranges, n * sizeof(int2)));
+  GB_TRY(hipMalloc((void**)&parent_internal, n * sizeof(int)));
+  GB_TRY(hipMalloc((void**)&parent_leaf, n * sizeof(int)));
+  GB_TRY(hipMalloc((void**)&qparams, 12 * sizeof(float)));
+  GB_TRY(hipMalloc((void**)&out.nodes, (size_t)(n - 1) * sizeof(BvhNodeQ)));
+  GB_TRY(hipMalloc((void**)&out.tris, (size_t)n * 3 * sizeof(float4)));
+
+  hipLaunchKernelGGL(k_init_bounds, dim3(1), dim3(64), 0, s, cbounds);
+  hipLaunchKernelGGL(k_tri_boxes, dim3(nb), dim3(256), 0, s, d_verts6, d_idx, n, tri_boxes, cbounds);
+  hipLaunchKernelGGL(k_morton, dim3(nb), dim3(256), 0, s, tri_boxes, n, cbounds, keys, vals);
+  size_t tmp_bytes = 0;
+  GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 30, s));
+  GB_TRY(hipMalloc(&tmp, tmp_bytes));
+  GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 30, s));
+  GB_TRY(hipMemsetAsync(flags, 0, n * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(k_radix_tree, dim3(nb), dim3(256), 0, s, keys2, (int)n, children, ranges, parent_internal, parent_leaf);
+  hipLaunchKernelGGL(k_propagate, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, parent_internal, parent_leaf, node_boxes, flags);
+  hipLaunchKernelGGL(k_quant_params, dim3(1), dim3(64), 0, s, node_boxes, qparams);
+  hipLaunchKernelGGL(k_emit_nodes, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, ranges, node_boxes, qparams, out.nodes, max_leaf);
+  hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, s, d_verts6, d_idx, vals2, n, out.tris);
+  float h[12];
+  GB_TRY(hipMemcpyAsync(h, qparams, sizeof(h), hipMemcpyDeviceToHost, s));
+  GB_TRY(hipStreamSynchronize(s));
+  GB_TRY(hipGetLastError());
+  for (int k = 0; k < 3; k++) { out.q_lo[k] = h[k]; out.q_scale[k] = h[3 + k]; out.bounds_lo[k] = h[6 + k]; out.bounds_hi[k] = h[9 + k]; }
+  out.n_nodes = n - 1; out.n_tris = n;
+  BvhNodeQ* keep_nodes = out.nodes; float4* keep_tris = out.tris;
+  out.nodes = nullptr; out.tris = nullptr;   // cleanup() must not free the results
+  cleanup();
+  out.nodes = keep_nodes; out.tris = keep_tris;
+  return 0;
+}
+
+void free_blas_gpu(GpuBlas& b) {
+  if (b.nodes) hipFree(b.nodes);
+  if (b.tris) hipFree(b.tris);
+  b = GpuBlas{};
+}
+
+void launch_rebase_nodes(const BvhNodeQ* src, BvhNodeQ* dst, uint32_t n, int node_base, uint32_t tri_base, hipStream_t s) {
+  if (n) hipLaunchKernelGGL(k_rebase_nodes, dim3((n + 255u) / 256u), dim3(256), 0, s, src, dst, n, node_base, tri_base);
+}
+
+}  // namespace rt

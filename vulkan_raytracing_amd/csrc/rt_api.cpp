@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "bvh_build.h"
+#include "bvh_gpu.h"
 #include "rt_device.h"
 #include "rt_kernels.h"
 
@@ -33,6 +34,8 @@ thread_local std::string g_create_error;
 struct Mesh {
   rt_mesh_range range{};
   bool built = false;
+  bool gpu_built = false;   // BLAS built on the device (bvh_gpu.hip): qnodes/tris hold its downloaded result, bvh/bvh4 stay empty
+  Aabb bounds{};
   BuiltBvh bvh;
   Bvh4 bvh4;
   std::vector<BvhNodeQ> qnodes;   // quantized form of bvh.nodes
@@ -94,6 +97,7 @@ struct rt_ctx {
   uint32_t* d_counters = nullptr;
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
+  int blas_builder = 1;          // 1: device LBVH (bvh_gpu.hip, default), 0: host binned-SAH
   bool timing = false;
   bool counting = false;
   std::vector<hipEvent_t> ev_pool;
@@ -165,14 +169,14 @@ int link_blas(rt_ctx* c) {
   for (auto& m : c->meshes) {
     if (!m.built) continue;
     m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt; m.node_base4 = (int32_t)nn4;
-    nn += m.bvh.nodes.size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
+    nn += m.gpu_built ? m.qnodes.size() : m.bvh.nodes.size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
   }
   std::vector<BvhNodeQ> nodes(nn);
   std::vector<Bvh4Node> nodes4(nn4);
   std::vector<TriPacket> tris(nt);
   for (auto& m : c->meshes) {
     if (!m.built) continue;
-    quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
+    if (!m.gpu_built) quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
     for (size_t i = 0; i < m.qnodes.size(); i++) {
       BvhNodeQ n = m.qnodes[i];
       auto fix = [&](int32_t ch) -> int32_t {
@@ -429,6 +433,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
+  if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TRACE_VARIANT")) c->cfg.variant = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   *out_ctx = c;
@@ -484,8 +489,27 @@ int rt_build_blas(rt_ctx* c, int mesh) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
   Mesh& m = c->meshes[mesh];
-  build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
-  collapse_bvh4(m.bvh, true, false, m.bvh4);
+  m.gpu_built = false;
+  if (c->blas_builder == 1 && c->cfg.variant == 0 && m.range.prim_count >= 8) {
+    // device build: LBVH straight from the uploaded vertex/index buffers; the result is downloaded once so that the
+    // linker treats every mesh alike
+    HIP_TRY(c, hipSetDevice(c->device));
+    GpuBlas g; std::string err;
+    if (build_blas_gpu(c->d_verts + m.range.first_float, c->d_idx + m.range.first_index, m.range.prim_count, c->stream, g, err))
+      return fail(c, RT_ERR_DEVICE, err);
+    m.qnodes.resize(g.n_nodes); m.tris.resize(g.n_tris);
+    hipError_t e1 = hipMemcpy(m.qnodes.data(), g.nodes, (size_t)g.n_nodes * sizeof(BvhNodeQ), hipMemcpyDeviceToHost);
+    hipError_t e2 = hipMemcpy(m.tris.data(), g.tris, (size_t)g.n_tris * sizeof(TriPacket), hipMemcpyDeviceToHost);
+    for (int k = 0; k < 3; k++) { m.q_lo[k] = g.q_lo[k]; m.q_scale[k] = g.q_scale[k]; m.bounds.lo[k] = g.bounds_lo[k]; m.bounds.hi[k] = g.bounds_hi[k]; }
+    free_blas_gpu(g);
+    HIP_TRY(c, e1); HIP_TRY(c, e2);
+    m.bvh = BuiltBvh{}; m.bvh4 = Bvh4{};
+    m.gpu_built = true;
+  } else {
+    build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
+    collapse_bvh4(m.bvh, true, false, m.bvh4);
+    m.bounds = m.bvh.bounds;
+  }
   m.built = true;
   c->blas_linked = false; c->tlas_valid = false;
   return RT_OK;
@@ -518,13 +542,17 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     d.first_float = (uint32_t)m.range.first_float;
     d.first_index = (uint32_t)m.range.first_index;
     d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0;
-    boxes[i] = instance_world_box(d.o2w, m.bvh.bounds);
+    boxes[i] = instance_world_box(d.o2w, m.bounds);
   }
   if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
   else { build_bvh(boxes.data(), (uint32_t)n, 1, 20, c->tlas); collapse_bvh4(c->tlas, false, true, c->tlas4); }
   // the quad traversal keeps its whole stack in LDS: bottom sentinel + TLAS + marker + deepest BLAS
   int blas_need = 0;
-  for (int i = 0; i < n; i++) blas_need = std::max(blas_need, c->meshes[inst[i].mesh].bvh4.stack_need);
+  for (int i = 0; i < n; i++) {
+    const Mesh& m = c->meshes[inst[i].mesh];
+    if (m.gpu_built && c->cfg.variant == 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "device-built BLAS is traversed by trace_variant 0 only: set trace_variant before rt_build_blas or use blas_builder 0");
+    blas_need = std::max(blas_need, m.bvh4.stack_need);
+  }
   if (1 + c->tlas4.stack_need + 1 + blas_need > STACK4_LDS)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
                     " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
@@ -565,12 +593,32 @@ int rt_shard_rows(int height, int band_rows, int shard, int n_shards) {
 int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (!c || !name) return RT_ERR_INVALID_ARGUMENT;
   std::string k(name);
-  if (k == "trace_variant") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0 or 1"); c->cfg.variant = value; return RT_OK; }
+  if (k == "trace_variant") {
+    if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0 or 1");
+    c->cfg.variant = value;
+    if (value == 1) {
+      // the quad kernel walks the BVH4 that only the host builder produces: rebuild device-built meshes on the host
+      bool rebuilt = false;
+      for (size_t mi = 0; mi < c->meshes.size(); mi++) {
+        Mesh& m = c->meshes[mi];
+        if (!m.built || !m.gpu_built) continue;
+        build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
+        collapse_bvh4(m.bvh, true, false, m.bvh4);
+        m.bounds = m.bvh.bounds; m.gpu_built = false; rebuilt = true;
+      }
+      if (rebuilt) {
+        c->blas_linked = false;
+        if (c->tlas_valid) { std::vector<rt_instance> keep = c->h_inst; c->tlas_valid = false; return rt_set_instances(c, keep.data(), (int)keep.size(), 0); }
+      }
+    }
+    return RT_OK;
+  }
   if (k == "trace_blocks_per_cu") {
     if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
     if (c->d_ovf && value * c->n_cu > c->cfg.trace_blocks) { hipFree(c->d_ovf); c->d_ovf = nullptr; }
     c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
   }
+  if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); c->blas_builder = value; return RT_OK; }
   if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
   if (k == "trace_min_blocks") { if (value < 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_min_blocks must be >= 8"); c->cfg.min_blocks = value; return RT_OK; }
   if (k == "shade_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "shade_blocks_per_cu must be 1..16"); c->cfg.shade_blocks = c->n_cu * value; return RT_OK; }
