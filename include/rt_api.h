@@ -166,6 +166,12 @@ int rt_intersect(rt_ctx* ctx, size_t n, const float* rays8_host, int any_hit, rt
 /* Same frame as rt_trace but through the instrumented traversal kernels (visit counters). */
 int rt_trace_counting(rt_ctx* ctx, int width, int height, float* out_rgba32f_host, rt_stats* stats);
 
+/* Host-only self check of the acceleration-structure builders (needs no GPU): builds the BVH2 / BVH4 / quantized nodes of
+ * an indexed mesh as rt_build_blas(blas_builder 0) does and verifies their invariants (every triangle in exactly one leaf,
+ * children inside parents, quantized boxes containing float boxes, depth and stack bounds).  out[8] = nodes, leaves,
+ * depth, max leaf size, BVH4 nodes, BVH4 stack need, violations, triangles reached.  0 = all invariants hold. */
+int rt_debug_check_builders(const float* verts6, size_t n_floats, const uint32_t* idx, size_t n_idx, uint64_t* out8);
+
 /* Message of the last failing call on this context (or of rt_create when ctx==NULL). */
 const char* rt_last_error(const rt_ctx* ctx);
 /* "gfx950 <device name> CUs=<n>" of the bound device. */

@@ -35,7 +35,7 @@ class RtStats(C.Structure):
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
            "rt_trace", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
-           "rt_trace_counting", "rt_set_param", "rt_last_error", "rt_device_info", "rt_abi_version"]
+           "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
 _LIB = None
 
@@ -61,6 +61,7 @@ def lib():
         L.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
         L.rt_set_timing.argtypes = [vp, C.c_int]
         L.rt_set_param.argtypes = [vp, C.c_char_p, C.c_int]
+        L.rt_debug_check_builders.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
         L.rt_intersect.argtypes = [vp, C.c_size_t, vp, C.c_int, vp, C.c_int, C.POINTER(RtStats)]
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p
@@ -176,3 +177,13 @@ class RtContext:
         st = RtStats()
         self._chk(self.L.rt_intersect(self.h, len(rays8), _p(rays8), int(any_hit), _p(out), int(counting), C.byref(st)), "rt_intersect")
         return out, st
+
+
+def check_builders(verts6, idx):
+    """rt_debug_check_builders: host-only invariants of the BVH builders; returns (status, stats dict)."""
+    verts6 = np.ascontiguousarray(verts6, np.float32)
+    idx = np.ascontiguousarray(idx, np.uint32)
+    out = np.zeros(8, np.uint64)
+    rc = lib().rt_debug_check_builders(_p(verts6), verts6.size, _p(idx), idx.size, _p(out))
+    keys = ("nodes", "leaves", "depth", "max_leaf", "bvh4_nodes", "bvh4_stack_need", "violations", "reached")
+    return rc, dict(zip(keys, (int(x) for x in out)))

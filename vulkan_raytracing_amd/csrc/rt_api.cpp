@@ -625,6 +625,81 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   return fail(c, RT_ERR_INVALID_ARGUMENT, "unknown parameter " + k);
 }
 
+// Host-only self check of the acceleration-structure builders (no device needed): builds the BVH2 of an indexed
+// triangle mesh exactly as rt_build_blas(blas_builder 0) does, collapses it to the BVH4, quantizes it, and verifies
+// the structural invariants.  out[0..7] = nodes, leaves, depth, max leaf size, bvh4 nodes, bvh4 stack need,
+// violations found, triangles reached.  Returns 0 when every invariant holds.
+int rt_debug_check_builders(const float* verts6, size_t n_floats, const uint32_t* idx, size_t n_idx, uint64_t* out) {
+  if (!verts6 || !idx || !out || n_idx % 3 != 0) return RT_ERR_INVALID_ARGUMENT;
+  const uint32_t n = (uint32_t)(n_idx / 3);
+  for (size_t k = 0; k < n_idx; k++) if ((size_t)idx[k] * 6 + 5 >= n_floats) return RT_ERR_INVALID_ARGUMENT;
+  BuiltBvh bvh; std::vector<TriPacket> tris; Bvh4 b4; std::vector<BvhNodeQ> q; float q_lo[3], q_scale[3];
+  build_blas(verts6, idx, n, bvh, tris);
+  collapse_bvh4(bvh, true, false, b4);
+  quantize_bvh2(bvh, q, q_lo, q_scale);
+  uint64_t violations = 0, reached = 0, max_leaf = 0;
+  std::vector<uint8_t> seen(n, 0);
+  auto tri_box = [&](uint32_t leaf_pos, Aabb& b) {
+    const TriPacket& t = tris[leaf_pos];
+    for (int k = 0; k < 3; k++) {
+      float a = t.v0[k], c1 = t.v0[k] + t.e1[k], c2 = t.v0[k] + t.e2[k];
+      b.lo[k] = std::min(a, std::min(c1, c2)); b.hi[k] = std::max(a, std::max(c1, c2));
+    }
+  };
+  // walk the float BVH2 and its quantized twin together
+  struct Item { int32_t ref; Aabb box; int depth; };
+  std::vector<Item> stack;
+  auto child_box = [&](const BvhNode& nd, int which) { Aabb b; if (which == 0) { b.lo[0] = nd.a[0]; b.hi[0] = nd.a[1]; b.lo[1] = nd.a[2]; b.hi[1] = nd.a[3]; b.lo[2] = nd.c[0]; b.hi[2] = nd.c[1]; }
+                                                        else { b.lo[0] = nd.b[0]; b.hi[0] = nd.b[1]; b.lo[1] = nd.b[2]; b.hi[1] = nd.b[3]; b.lo[2] = nd.c[2]; b.hi[2] = nd.c[3]; } return b; };
+  Aabb all; for (int k = 0; k < 3; k++) { all.lo[k] = -3e38f; all.hi[k] = 3e38f; }
+  stack.push_back({0, all, 0});
+  int depth = 0;
+  while (!stack.empty()) {
+    Item it = stack.back(); stack.pop_back();
+    depth = std::max(depth, it.depth);
+    if (it.ref >= 0) {
+      if ((size_t)it.ref >= bvh.nodes.size()) { violations++; continue; }
+      const BvhNode& nd = bvh.nodes[it.ref]; const BvhNodeQ& nq = q[it.ref];
+      for (int w = 0; w < 2; w++) {
+        Aabb cb = child_box(nd, w);
+        const int32_t ref = w ? nd.child1 : nd.child0;
+        if (cb.lo[0] > 1e37f) continue;   // missing child of a synthetic root
+        for (int k = 0; k < 3; k++) {
+          if (cb.lo[k] < it.box.lo[k] - 1e-4f || cb.hi[k] > it.box.hi[k] + 1e-4f) violations++;      // child inside parent
+          const uint32_t wq = nq.w[(w ? 3 : 0) + k];
+          const double qlo = (double)q_lo[k] + (double)(wq & 0xFFFFu) * q_scale[k], qhi = (double)q_lo[k] + (double)(wq >> 16) * q_scale[k];
+          if (qlo > cb.lo[k] || qhi < cb.hi[k]) violations++;                                         // quantized box contains the float box
+        }
+        if ((w ? nq.child1 : nq.child0) != ref) violations++;
+        stack.push_back({ref, cb, it.depth + 1});
+      }
+    } else {
+      const uint32_t r = (uint32_t)(~it.ref), first = r >> 3, count = (r & 7u) + 1u;
+      max_leaf = std::max<uint64_t>(max_leaf, count);
+      for (uint32_t k = 0; k < count; k++) {
+        if (first + k >= n) { violations++; continue; }
+        const uint32_t prim = tris[first + k].prim;
+        if (prim >= n || seen[prim]) violations++; else { seen[prim] = 1; reached++; }
+        Aabb tb; tri_box(first + k, tb);
+        for (int a = 0; a < 3; a++) if (tb.lo[a] < it.box.lo[a] - 1e-4f || tb.hi[a] > it.box.hi[a] + 1e-4f) violations++;   // triangle inside its leaf box
+      }
+    }
+  }
+  if (reached != n) violations++;
+  // BVH4: every triangle reachable exactly once as well
+  std::vector<uint8_t> seen4(n, 0); uint64_t reached4 = 0;
+  std::vector<int32_t> st4; if (!b4.nodes.empty()) st4.push_back(0);
+  while (!st4.empty()) {
+    int32_t ref = st4.back(); st4.pop_back();
+    if (ref >= 0) { for (int k = 0; k < 4; k++) { int32_t c = b4.nodes[ref].c[k].ref; if (c != 0x7FFFFFFF) st4.push_back(c); } }
+    else { const uint32_t r = (uint32_t)(~ref), first = r >> 3, count = (r & 7u) + 1u; for (uint32_t k = 0; k < count && first + k < n; k++) { uint32_t p = tris[first + k].prim; if (p < n && !seen4[p]) { seen4[p] = 1; reached4++; } else violations++; } }
+  }
+  if (reached4 != n) violations++;
+  out[0] = bvh.nodes.size(); out[1] = bvh.leaves; out[2] = (uint64_t)depth; out[3] = max_leaf; out[4] = b4.nodes.size(); out[5] = (uint64_t)b4.stack_need;
+  out[6] = violations; out[7] = reached;
+  return violations ? RT_ERR_INVALID_ARGUMENT : RT_OK;
+}
+
 int rt_set_timing(rt_ctx* c, int enabled) { if (!c) return RT_ERR_INVALID_ARGUMENT; c->timing = enabled != 0; return RT_OK; }
 
 int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t out_capacity_bytes, void* hip_stream) {
