@@ -303,6 +303,9 @@ constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both
 #ifndef RT_KEEP_NUM
 #define RT_KEEP_NUM 5   /* interior loop continues while >= RT_KEEP_NUM/8 of the live lanes are interior */
 #endif
+#ifndef RT_INTERIOR_UNROLL
+#define RT_INTERIOR_UNROLL 2
+#endif
 #ifndef RT_STACK2_LDS
 #define RT_STACK2_LDS 12   /* 12 entries in LDS (3 KB per wave) let 6 blocks share a CU; deeper paths spill to HBM */
 #endif
@@ -426,13 +429,10 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
     const uint32_t live = 64u - (uint32_t)__builtin_popcountll(__ballot(need));
     const uint32_t keep_going = (live * RT_KEEP_NUM + 7u) >> 3;   // share of the live lanes that must still be interior
 
-    // ---- (B) interior-node loop: runs while most live lanes are at interior nodes
-    for (;;) {
-      const bool interior = cur >= 0;   // idle lanes hold REF_DONE
-      const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(interior));
-      if (n_int == 0 || n_int < keep_going) break;
-      if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
-      if (interior) {
+    // ---- (B) interior-node loop: runs while most live lanes are at interior nodes.  The exit vote (ballot, popcount,
+    // compare) is taken every RT_INTERIOR_UNROLL trips; in between, lanes that left the interior state just idle.
+    auto interior_step = [&]() {
+      if (cur >= 0) {   // idle lanes hold REF_DONE
         const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
         const uint4 Q0 = np[0], Q1 = np[1];
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
@@ -448,6 +448,13 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
         else if (h1) cur = ch.y;
         else pop();
       }
+    };
+    for (;;) {
+      const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(cur >= 0));
+      if (n_int == 0 || n_int < keep_going) break;
+      if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
+#pragma unroll
+      for (int r = 0; r < RT_INTERIOR_UNROLL; r++) interior_step();
     }
 
     // ---- (C) the rarer bodies, each run once for all lanes that wait at them.  They are chained (leaf, then

@@ -428,7 +428,8 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   c->info = std::string("gfx950 ") + prop.name + " CUs=" + std::to_string(prop.multiProcessorCount);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_DEVICE, "hipStreamCreate failed"); }
   // persistent grids: ~27 KB of LDS and <= 84 VGPRs per 256-thread block admit 5-6 blocks per CU
-  c->cfg.trace_blocks = c->n_cu * 6;
+  // (4 measured best with three frames in flight: the other frames' kernels need room; 6 is best for a lone frame)
+  c->cfg.trace_blocks = c->n_cu * 4;
   c->cfg.shade_blocks = c->n_cu * 8;
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
