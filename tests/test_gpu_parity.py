@@ -339,3 +339,75 @@ def test_device_built_blas_gives_identical_results(ctx):
     assert np.array_equal(g[:2000]["prim"], o["prim"]) and np.array_equal(g[:2000]["t"].view(np.uint32), o["t"].view(np.uint32))
     # LBVH quality: more visits than SAH, but the same order of magnitude
     assert st.node_visits < 3 * sth.node_visits
+
+
+def test_reference_default_bounce_budget_63(ctx):
+    """The reference's own defaults: MAX_BOUNCE_COUNT 63 (include/config.h:26) with a refractive and a mirror object —
+    exercises deep bounce queues and the host-side early exit once every path has ended."""
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 2, 1, 63, 2,
+                                 sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.8)
+    W, H = 160, 96
+    gpu, st = ctx.trace(W, H)
+    ref, rc = sp.orc.render(W, H)
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    assert st.rays_secondary > st.rays_primary // 50
+
+
+def test_general_affine_and_masked_instances(ctx):
+    """Instance transforms with rotation about an arbitrary axis and NON-UNIFORM scale (normals need the inverse
+    transpose, src/shader.rchit:94), plus an instance with mask 0 that must be invisible (ray mask 0xFF & 0 == 0)."""
+    paths = [os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj")]
+
+    def affine(axis, ang, scale, trans):
+        a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        R = np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+        M = R @ np.diag(scale)
+        return np.concatenate([M, np.asarray(trans, np.float64)[:, None]], axis=1).astype(np.float32).reshape(12)
+
+    inst = np.zeros(4, scenes.INSTANCE_DTYPE)
+    inst[0] = host.make_instance(affine((1, 2, 3), 0.7, (1.0, 0.5, 1.6), (-2.0, 0.5, 0.0)), 0, 0)
+    inst[1] = host.make_instance(affine((0, 1, 1), -1.1, (2.0, 0.7, 0.9), (3.0, -1.0, 4.0)), 1, 1)
+    inst[2] = host.make_instance(affine((1, 0, 0), 0.3, (1.5, 1.5, 0.4), (0.5, 2.5, 6.0)), 1, 0)
+    hidden = host.make_instance(affine((0, 0, 1), 0.0, (6.0, 6.0, 6.0), (0.0, 0.0, 10.0)), 0, 1)
+    hidden["custom_index_and_mask"] = 0 | (0x00 << 24)      # mask 0: a huge cube right in front of the camera, never hit
+    inst[3] = hidden
+    geom = host.SceneGeometry(paths)
+    u = host.default_uniforms(max_bounce_count=3, samples_per_pixel=2, center_object_type=1, orbiting_object_type=0,
+                              orbiting_object_primitive_offset=geom.orbiting_primitive_offset, orbiting_object_vertex_offset=geom.orbiting_vertex_offset)
+    sp = scenes.ScenePair(paths, inst, u, sky=scenes.synthetic_skybox(64), ctx=ctx)
+    W, H = 256, 144
+    gpu, st = ctx.trace(W, H)
+    ref, rc = sp.orc.render(W, H)
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    rays = scenes.random_rays(5000, seed=5, target_radius=6.0)
+    g, _ = ctx.intersect(rays)
+    o = sp.orc.intersect(rays, use_bvh=False)
+    assert np.array_equal(g, o) and not np.any(g["inst"] == 3) and np.any(g["inst"] == 2)
+
+
+def test_cfg4_size_properties(ctx):
+    """BASELINE config 4 size (3840x2160, depth 6): too big for the oracle, so size-independent properties only —
+    determinism, alpha, ray bookkeeping, and 8 logical shards == the full frame bit for bit."""
+    import torch
+    arm, _ = host.armadillo_path(RES)
+    scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 5, 4, sky=scenes.synthetic_skybox(128), ctx=ctx, time_param=1.3)
+    W, H = 3840, 2160
+    a, st = ctx.trace(W, H)
+    assert st.rays_primary == W * H * 4 and st.rays_secondary > 0 and st.rays_shadow > 0
+    assert np.all(a[..., 3] == 1.0) and np.isfinite(a).all()
+    n = 8
+    rows_max = tiling.max_shard_rows(H, tiling.BAND_ROWS, n)
+    shards = []
+    total = 0
+    for s in range(n):
+        buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+        ctx.trace_shard(W, H, tiling.BAND_ROWS, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+        stt = ctx.stats()
+        total += stt.rays_primary + stt.rays_secondary + stt.rays_shadow
+        torch.cuda.synchronize()
+        shards.append(buf.cpu().numpy())
+    assert np.array_equal(tiling.assemble(shards, H, W, tiling.BAND_ROWS), a)
+    assert total == st.rays_primary + st.rays_secondary + st.rays_shadow
