@@ -308,9 +308,12 @@ def test_headless_cpp_host_matches_python_path(tmp_path):
     assert np.abs(ppm - np.clip(img[..., :3], 0, 1)).max() <= 0.5 / 255 + 1e-6
 
 
-def test_device_built_blas_gives_identical_results(ctx):
-    """rt_build_blas with blas_builder = 1 builds the BLAS on the GPU (LBVH, csrc/bvh_gpu.hip).  Any valid BVH
-    yields the same hits, so records and images must equal those of the host SAH builder and of the oracle."""
+@pytest.mark.parametrize("algo", ["1", "2"])
+def test_device_built_blas_gives_identical_results(ctx, algo, monkeypatch):
+    """rt_build_blas with blas_builder = 1 builds the BLAS on the GPU (csrc/bvh_gpu.hip: LBVH = algo 1, the default, or
+    PLOC = algo 2).  Any valid BVH yields the same hits, so records and images must equal those of the host SAH builder
+    and of the oracle."""
+    monkeypatch.setenv("RT_GPU_BVH_ALGO", algo)
     arm, _ = host.armadillo_path(RES)
     rays = scenes.random_rays(30000, seed=77, target_radius=5.0)
     c2 = RtContext(0)

@@ -218,6 +218,94 @@ __global__ __launch_bounds__(256) void k_rebase_nodes(const BvhNodeQ* src, BvhNo
   dst[i] = q;
 }
 
+// ---- PLOC: parallel locally-ordered clustering (Meister & Bittner, "Parallel Locally-Ordered Clustering for Bounding
+// Volume Hierarchy Construction", TVCG 2018).  Clusters start as the Morton-sorted triangles; every round each
+// cluster looks at its 2r neighbours in the sorted order for the partner that minimises the surface area of the merged
+// box, mutually-nearest pairs merge into a new node, survivors are compacted in order.  Bottom-up, so every node is
+// born with the boxes of both children; the result is close to a top-down SAH tree at a fraction of its build time.
+struct Cluster { Box box; int id; int pad; };        // id >= 0: internal node, < 0: leaf ~sorted position
+struct PlocNode { Box b0, b1; int c0, c1; };          // 56 bytes
+
+__device__ __forceinline__ float merged_area(const Box& a, const Box& b) {
+  const float dx = fmaxf(a.hi[0], b.hi[0]) - fminf(a.lo[0], b.lo[0]);
+  const float dy = fmaxf(a.hi[1], b.hi[1]) - fminf(a.lo[1], b.lo[1]);
+  const float dz = fmaxf(a.hi[2], b.hi[2]) - fminf(a.lo[2], b.lo[2]);
+  return dx * dy + dy * dz + dz * dx;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_init(const Box* tri_boxes, const uint32_t* sorted_ids, int n, Cluster* c) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  Cluster cl; cl.box = tri_boxes[sorted_ids[i]]; cl.id = ~i; cl.pad = 0;
+  c[i] = cl;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_nn(const Cluster* c, int m, int r, int* nn) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const Box me = c[i].box;
+  float best = 3.0e38f; int bj = i == 0 ? 1 : i - 1;
+  const int lo = max(0, i - r), hi = min(m - 1, i + r);
+  for (int j = lo; j <= hi; j++) {
+    if (j == i) continue;
+    const float a = merged_area(me, c[j].box);
+    if (a < best) { best = a; bj = j; }     // ascending j: ties keep the smaller index, so the choice is deterministic
+  }
+  nn[i] = bj;
+}
+
+// flags: bit 0 = cluster survives (possibly as a merged one), bit 1 = this slot creates a new node
+__global__ __launch_bounds__(256) void k_ploc_flags(int m, const int* nn, uint32_t* survive, uint32_t* creates) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const int j = nn[i];
+  const bool mutual = nn[j] == i;
+  survive[i] = (mutual && i > j) ? 0u : 1u;
+  creates[i] = (mutual && i < j) ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_ploc_merge(const Cluster* c, int m, const int* nn, const uint32_t* survive, const uint32_t* pos, const uint32_t* creates,
+                                                    const uint32_t* cpos, int node_base, PlocNode* nodes, Cluster* next) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m || !survive[i]) return;
+  Cluster out = c[i];
+  if (creates[i]) {
+    const Cluster o = c[nn[i]];
+    const int id = node_base + (int)cpos[i];          // ids follow the sorted order: the numbering is deterministic
+    PlocNode nd; nd.b0 = out.box; nd.b1 = o.box; nd.c0 = out.id; nd.c1 = o.id;
+    nodes[id] = nd;
+    for (int k = 0; k < 3; k++) { out.box.lo[k] = fminf(out.box.lo[k], o.box.lo[k]); out.box.hi[k] = fmaxf(out.box.hi[k], o.box.hi[k]); }
+    out.id = id;
+  }
+  next[pos[i]] = out;
+}
+
+__global__ void k_quant_params_ploc(const PlocNode* nodes, int root, float* qparams) {
+  if (threadIdx.x >= 3) return;
+  const int k = threadIdx.x;
+  const float lo = fminf(nodes[root].b0.lo[k], nodes[root].b1.lo[k]), hi = fmaxf(nodes[root].b0.hi[k], nodes[root].b1.hi[k]);
+  const float ext = hi - lo;
+  const float scale = ext > 0.f ? ext * 1.00001f / 65520.0f : 1e-30f;
+  qparams[k] = lo - 4.0f * scale;
+  qparams[3 + k] = scale;
+  qparams[6 + k] = lo; qparams[9 + k] = hi;
+}
+
+// node id k (creation order, root = n-2) -> array slot (n-2) - k, so the root lands in slot 0
+__global__ __launch_bounds__(256) void k_emit_ploc(const PlocNode* nodes, int n_internal, const float* qparams, BvhNodeQ* out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_internal) return;
+  const PlocNode nd = nodes[k];
+  BvhNodeQ q{};
+  for (int a = 0; a < 3; a++) {
+    q.w[a] = quant_box_axis(nd.b0.lo[a], nd.b0.hi[a], qparams[a], qparams[3 + a]);
+    q.w[3 + a] = quant_box_axis(nd.b1.lo[a], nd.b1.hi[a], qparams[a], qparams[3 + a]);
+  }
+  q.child0 = nd.c0 >= 0 ? (n_internal - 1 - nd.c0) : ~(int)(((uint32_t)(~nd.c0) << 3) | 0u);
+  q.child1 = nd.c1 >= 0 ? (n_internal - 1 - nd.c1) : ~(int)(((uint32_t)(~nd.c1) << 3) | 0u);
+  out[n_internal - 1 - k] = q;
+}
+
 #define GB_TRY(expr)                                                                                             \
   do {                                                                                                           \
     hipError_t e_ = (expr);                                                                                      \
@@ -267,6 +355,54 @@ int build_blas_gpu(const float* d_verts6, const uint32_t* d_idx, uint32_t n, hip
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 30, s));
   GB_TRY(hipMalloc(&tmp, tmp_bytes));
   GB_TRY(hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, keys, keys2, vals, vals2, (int)n, 0, 30, s));
+  int algo = 1;   // 1: LBVH (Karras radix tree, default — 1.17 ms/frame on cfg3), 2: PLOC (1.20 ms/frame on this smooth mesh)
+  if (const char* e = getenv("RT_GPU_BVH_ALGO")) { int v = atoi(e); if (v == 1 || v == 2) algo = v; }
+  if (algo == 2) {
+    int radius = 16;
+    if (const char* e = getenv("RT_PLOC_RADIUS")) { int v = atoi(e); if (v >= 1 && v <= 128) radius = v; }
+    Cluster *ca = nullptr, *cb = nullptr; PlocNode* pn = nullptr; int* nn = nullptr; uint32_t *sv = nullptr, *cr = nullptr, *ps = nullptr, *cp = nullptr; void* scan_tmp = nullptr;
+    auto cleanup2 = [&]() { for (void* p : {(void*)ca, (void*)cb, (void*)pn, (void*)nn, (void*)sv, (void*)cr, (void*)ps, (void*)cp, scan_tmp}) if (p) hipFree(p); };
+#define PL_TRY(expr) do { hipError_t e2_ = (expr); if (e2_ != hipSuccess) { err = std::string("HIP runtime exception: return code ") + std::to_string((int)e2_) + " in " #expr; cleanup2(); cleanup(); return 1; } } while (0)
+    PL_TRY(hipMalloc((void**)&ca, n * sizeof(Cluster))); PL_TRY(hipMalloc((void**)&cb, n * sizeof(Cluster)));
+    PL_TRY(hipMalloc((void**)&pn, (size_t)(n - 1) * sizeof(PlocNode))); PL_TRY(hipMalloc((void**)&nn, n * sizeof(int)));
+    PL_TRY(hipMalloc((void**)&sv, n * sizeof(uint32_t))); PL_TRY(hipMalloc((void**)&cr, n * sizeof(uint32_t)));
+    PL_TRY(hipMalloc((void**)&ps, n * sizeof(uint32_t))); PL_TRY(hipMalloc((void**)&cp, n * sizeof(uint32_t)));
+    size_t scan_bytes = 0;
+    PL_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scan_bytes, sv, ps, (int)n, s));
+    PL_TRY(hipMalloc(&scan_tmp, scan_bytes));
+    hipLaunchKernelGGL(k_ploc_init, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, ca);
+    int m = (int)n, node_base = 0, rounds = 0;
+    while (m > 1) {
+      const uint32_t mb = ((uint32_t)m + 255u) / 256u;
+      hipLaunchKernelGGL(k_ploc_nn, dim3(mb), dim3(256), 0, s, ca, m, radius, nn);
+      hipLaunchKernelGGL(k_ploc_flags, dim3(mb), dim3(256), 0, s, m, nn, sv, cr);
+      PL_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, sv, ps, m, s));
+      PL_TRY(hipcub::DeviceScan::ExclusiveSum(scan_tmp, scan_bytes, cr, cp, m, s));
+      hipLaunchKernelGGL(k_ploc_merge, dim3(mb), dim3(256), 0, s, ca, m, nn, sv, ps, cr, cp, node_base, pn, cb);
+      uint32_t last[4];   // pos[m-1], survive[m-1], cpos[m-1], creates[m-1]
+      PL_TRY(hipMemcpyAsync(&last[0], ps + (m - 1), 4, hipMemcpyDeviceToHost, s)); PL_TRY(hipMemcpyAsync(&last[1], sv + (m - 1), 4, hipMemcpyDeviceToHost, s));
+      PL_TRY(hipMemcpyAsync(&last[2], cp + (m - 1), 4, hipMemcpyDeviceToHost, s)); PL_TRY(hipMemcpyAsync(&last[3], cr + (m - 1), 4, hipMemcpyDeviceToHost, s));
+      PL_TRY(hipStreamSynchronize(s));
+      const int created = (int)(last[2] + last[3]);
+      if (created == 0) { err = "PLOC made no progress"; cleanup2(); cleanup(); return 1; }
+      m = (int)(last[0] + last[1]); node_base += created;
+      std::swap(ca, cb);
+      if (++rounds > 4096) { err = "PLOC did not converge"; cleanup2(); cleanup(); return 1; }
+    }
+    if (node_base != (int)n - 1) { err = "PLOC produced " + std::to_string(node_base) + " nodes for " + std::to_string(n) + " triangles"; cleanup2(); cleanup(); return 1; }
+    hipLaunchKernelGGL(k_quant_params_ploc, dim3(1), dim3(64), 0, s, pn, (int)n - 2, qparams);
+    hipLaunchKernelGGL(k_emit_ploc, dim3(nb), dim3(256), 0, s, pn, (int)n - 1, qparams, out.nodes);
+    hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, s, d_verts6, d_idx, vals2, n, out.tris);
+    float h2[12];
+    PL_TRY(hipMemcpyAsync(h2, qparams, sizeof(h2), hipMemcpyDeviceToHost, s));
+    PL_TRY(hipStreamSynchronize(s));
+    PL_TRY(hipGetLastError());
+    for (int k = 0; k < 3; k++) { out.q_lo[k] = h2[k]; out.q_scale[k] = h2[3 + k]; out.bounds_lo[k] = h2[6 + k]; out.bounds_hi[k] = h2[9 + k]; }
+    out.n_nodes = n - 1; out.n_tris = n;
+    cleanup2(); cleanup();
+    return 0;
+#undef PL_TRY
+  }
   GB_TRY(hipMemsetAsync(flags, 0, n * sizeof(uint32_t), s));
   hipLaunchKernelGGL(k_radix_tree, dim3(nb), dim3(256), 0, s, keys2, (int)n, children, ranges, parent_internal, parent_leaf);
   hipLaunchKernelGGL(k_propagate, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, parent_internal, parent_leaf, node_boxes, flags);
