@@ -414,3 +414,36 @@ def test_cfg4_size_properties(ctx):
         shards.append(buf.cpu().numpy())
     assert np.array_equal(tiling.assemble(shards, H, W, tiling.BAND_ROWS), a)
     assert total == st.rays_primary + st.rays_secondary + st.rays_shadow
+
+
+@pytest.mark.parametrize("algo", ["1", "2"])
+def test_device_builders_on_degenerate_soup(ctx, algo, monkeypatch, tmp_path):
+    """Duplicate Morton codes, coincident and zero-area triangles, all triangles in one plane: the device builders must
+    still produce a valid tree (checked against brute force through the oracle)."""
+    monkeypatch.setenv("RT_GPU_BVH_ALGO", algo)
+    rng = np.random.default_rng(11)
+    pts = np.repeat(rng.normal(size=(40, 3)), 8, axis=0)          # 320 vertices, only 40 distinct positions
+    pts[:80, 2] = 0.25                                            # a coplanar patch
+    tri = rng.integers(0, len(pts), size=(700, 3))
+    tri[:50] = tri[50:100]                                        # exact duplicates
+    p = tmp_path / "soup.obj"
+    with open(p, "w") as f:
+        for v in pts:
+            f.write("v %.6f %.6f %.6f\nvn 0 0 1\n" % tuple(v))
+        for t in tri:
+            f.write("f %d//%d %d//%d %d//%d\n" % (t[0] + 1, t[0] + 1, t[1] + 1, t[1] + 1, t[2] + 1, t[2] + 1))
+    c2 = RtContext(0)
+    try:
+        inst = [host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)]
+        u = host.default_uniforms(max_bounce_count=1, samples_per_pixel=1, center_object_type=0, orbiting_object_type=0)
+        sp = scenes.ScenePair([str(p)], inst, u, ctx=c2)
+        rays = scenes.random_rays(20000, seed=4, origin_radius=8.0, target_radius=2.5)
+        g, _ = c2.intersect(rays)
+        o = sp.orc.intersect(rays, use_bvh=False)
+        assert (o["inst"] >= 0).mean() > 0.2
+        assert np.array_equal(g, o)
+        sh = rays.copy(); sh[:, 7] = 7.0
+        ga, _ = c2.intersect(sh, any_hit=True)
+        assert np.array_equal(ga["inst"] >= 0, sp.orc.intersect(sh, use_bvh=False)["inst"] >= 0)
+    finally:
+        c2.close()
