@@ -213,13 +213,13 @@ def test_error_behaviour(ctx):
 
 
 def test_trace_variants_are_result_identical(ctx):
-    """BVH2/one-lane-per-ray and BVH4/four-lanes-per-ray kernels: identical hit records and images."""
+    """BVH2/one-lane-per-ray, BVH4/four-lanes-per-ray and 4-ary-record/one-lane kernels: identical hit records and images."""
     arm, _ = host.armadillo_path(RES)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 1, 4, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.6)
     rays = scenes.random_rays(40000, seed=33, target_radius=6.0)
     out = {}
     try:
-        for v in (0, 1):
+        for v in (0, 1, 2):
             ctx.set_param("trace_variant", v)
             g, _ = ctx.intersect(rays)
             sh = rays.copy(); sh[:, 7] = 17.0
@@ -228,9 +228,10 @@ def test_trace_variants_are_result_identical(ctx):
             out[v] = (g, ga["inst"] >= 0, img, (st.rays_primary, st.rays_secondary, st.rays_shadow))
     finally:
         ctx.set_param("trace_variant", 0)
-    assert np.array_equal(out[0][0], out[1][0])
-    assert np.array_equal(out[0][1], out[1][1])
-    assert np.array_equal(out[0][2], out[1][2]) and out[0][3] == out[1][3]
+    for v in (1, 2):
+        assert np.array_equal(out[0][0], out[v][0])
+        assert np.array_equal(out[0][1], out[v][1])
+        assert np.array_equal(out[0][2], out[v][2]) and out[0][3] == out[v][3]
     o = sp.orc.intersect(rays, use_bvh=True)
     same = (out[1][0]["prim"] == o["prim"]) & (out[1][0]["inst"] == o["inst"]) & (out[1][0]["t"].view(np.uint32) == o["t"].view(np.uint32))
     assert same.mean() >= 0.9999

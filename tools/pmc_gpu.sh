@@ -7,9 +7,10 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 CMD="python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline $@"
 i=0
-for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VMEM_WR" \
-           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU" \
-           "GRBM_GUI_ACTIVE" ; do
+# PMC_SETS="A B C;D E" overrides the counter sets (one rocprofv3 pass per ';'-separated set)
+DEFAULT_SETS="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VMEM_WR;SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_SALU;GRBM_GUI_ACTIVE"
+IFS=';' read -ra SETS <<< "${PMC_SETS:-$DEFAULT_SETS}"
+for set in "${SETS[@]}"; do
   i=$((i+1))
   echo "pass $i: $set" >> $OUT/progress.log
   timeout -k 10 150 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- $CMD > $OUT/p$i.log 2>&1 || echo "pass $i failed: $set" >> $OUT/progress.log

@@ -46,7 +46,7 @@ def main():
         ctx.set_param("trace_variant", v)
         _, cst = ctx.trace(W, H, counting=True)
         dg = list(cst.diag)
-        if v == 0:
+        if v in (0, 2):
             print(json.dumps({"variant": v, "diag_closest": {"interior_wave_trips": dg[0], "lanes_busy_per_interior_trip": round(dg[1] / max(1, dg[0]), 2), "wave_cycles": dg[2]},
                               "diag_shadow": {"interior_wave_trips": dg[3], "lanes_busy_per_interior_trip": round(dg[4] / max(1, dg[3]), 2), "wave_cycles": dg[5]}}), flush=True)
         if v == 1:

@@ -346,6 +346,45 @@ void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3
   }
 }
 
+void widen_bvh2(const BvhNodeQ* nodes, size_t count, int32_t base, WideNodeQ* out) {
+  for (size_t i = 0; i < count; i++) {
+    const BvhNodeQ& n = nodes[i];
+    uint32_t ex[4], ey[4], ez[4]; int32_t er[4]; int ne = 0;
+    auto add = [&](const uint32_t* w, int32_t ref) {
+      for (int j = 0; j < ne; j++) if (er[j] == ref) return;   // a missing child is stored as a copy of its sibling
+      ex[ne] = w[0]; ey[ne] = w[1]; ez[ne] = w[2]; er[ne] = ref; ne++;
+    };
+    auto expand = [&](const uint32_t* w, int32_t ref) {
+      if (ref >= 0) { const BvhNodeQ& c = nodes[ref - base]; add(c.w, c.child0); add(c.w + 3, c.child1); }
+      else add(w, ref);
+    };
+    expand(n.w, n.child0);
+    if (n.child1 != n.child0) expand(n.w + 3, n.child1);
+    WideNodeQ o;
+    for (int k = 0; k < 4; k++) {
+      if (k < ne) { o.x[k] = ex[k]; o.y[k] = ey[k]; o.z[k] = ez[k]; o.ref[k] = er[k]; }
+      else { o.x[k] = o.y[k] = o.z[k] = 0u; o.ref[k] = er[0]; }   // point box at quantum 0: below every stored plane
+    }
+    out[i] = o;
+  }
+}
+
+int bvh2_levels(const BvhNodeQ* nodes, size_t count, int32_t root) {
+  if (count == 0) return 0;
+  std::vector<std::pair<int32_t, int>> todo;
+  todo.push_back({root, 1});
+  int levels = 0; size_t seen = 0;
+  while (!todo.empty()) {
+    auto [i, d] = todo.back(); todo.pop_back();
+    if (i < 0 || (size_t)i >= count || ++seen > count) return -1;
+    levels = std::max(levels, d);
+    const BvhNodeQ& n = nodes[i];
+    if (n.child0 >= 0) todo.push_back({n.child0, d + 1});
+    if (n.child1 >= 0 && n.child1 != n.child0) todo.push_back({n.child1, d + 1});
+  }
+  return levels;
+}
+
 void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris) {
   std::vector<Aabb> boxes(n_prims);
   for (uint32_t p = 0; p < n_prims; p++) {

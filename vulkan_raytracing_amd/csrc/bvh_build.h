@@ -55,6 +55,13 @@ void refit_bvh4(const BuiltBvh& b2, Bvh4& b4);
 // of the tree's bounds.  A missing child (synthetic root of a one-leaf tree) becomes a copy of its sibling.
 void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]);
 
+// 4-ary records (rt_device.h WideNodeQ) of `count` linked quantized nodes: out[i] holds the grandchildren of
+// nodes[i].  Interior links are global indices; node g of this tree sits at nodes[g - base].
+void widen_bvh2(const BvhNodeQ* nodes, size_t count, int32_t base, WideNodeQ* out);
+// number of interior levels below (and including) node `root` of a quantized tree (links local to `nodes`);
+// returns -1 when the links do not form a tree of at most `count` nodes
+int bvh2_levels(const BvhNodeQ* nodes, size_t count, int32_t root);
+
 // BLAS helper: boxes + 48-byte packets for an indexed triangle mesh in the reference's layout
 // (positions at verts6[6*i .. 6*i+2], object-local uint32 indices).
 void build_blas(const float* verts6, const uint32_t* idx, uint32_t n_prims, BuiltBvh& bvh, std::vector<TriPacket>& tris);

@@ -138,20 +138,24 @@ __device__ __forceinline__ bool slab(float lox, float loy, float loz, float hix,
 }
 
 // Slab test on a quantized box (rt_device.h BvhNodeQ): w = lo | hi << 16 per axis; the ray space carries
-// qs = q_scale/d and qb = (q_lo - o)/d, so a plane distance is one cvt + one fma.
-__device__ __forceinline__ bool slab_q(uint32_t wx, uint32_t wy, uint32_t wz, F3 qs, F3 qb, float tmin, float tlim, float& tn) {
+// qs = q_scale/d and qb = (q_lo - o)/d, so a plane distance is one cvt + one fma.  Which plane of an axis is
+// the near one depends only on the sign of the ray direction, so instead of a min and a max per axis the
+// word is rotated by rot (0, or 16 for a negative direction) and its low half is the near plane.
+__device__ __forceinline__ bool slab_q(uint32_t wx, uint32_t wy, uint32_t wz, F3 qs, F3 qb, uint3 rot, float tmin, float tlim, float& tn) {
+  wx = __builtin_amdgcn_alignbit(wx, wx, rot.x); wy = __builtin_amdgcn_alignbit(wy, wy, rot.y); wz = __builtin_amdgcn_alignbit(wz, wz, rot.z);
   const float x0 = __builtin_fmaf((float)(wx & 0xFFFFu), qs.x, qb.x), x1 = __builtin_fmaf((float)(wx >> 16), qs.x, qb.x);
   const float y0 = __builtin_fmaf((float)(wy & 0xFFFFu), qs.y, qb.y), y1 = __builtin_fmaf((float)(wy >> 16), qs.y, qb.y);
   const float z0 = __builtin_fmaf((float)(wz & 0xFFFFu), qs.z, qb.z), z1 = __builtin_fmaf((float)(wz >> 16), qs.z, qb.z);
-  tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tlim));
+  tn = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+  const float tf = fminf(fminf(x1, y1), fminf(z1, tlim));
   return tn <= tf * 1.00002f;
 }
-// (qs, qb) of a ray in the space of a tree with dequantisation (q_lo, q_scale)
-__device__ __forceinline__ void quant_space(F3 o, F3 d, const float* q_lo, const float* q_scale, F3& qs, F3& qb) {
+// (qs, qb, rot) of a ray in the space of a tree with dequantisation (q_lo, q_scale)
+__device__ __forceinline__ void quant_space(F3 o, F3 d, const float* q_lo, const float* q_scale, F3& qs, F3& qb, uint3& rot) {
   const F3 id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
   qs = mk3(q_scale[0] * id.x, q_scale[1] * id.y, q_scale[2] * id.z);
   qb = mk3((q_lo[0] - o.x) * id.x, (q_lo[1] - o.y) * id.y, (q_lo[2] - o.z) * id.z);
+  rot = make_uint3(qs.x < 0.0f ? 16u : 0u, qs.y < 0.0f ? 16u : 0u, qs.z < 0.0f ? 16u : 0u);   // q_scale > 0: the sign of 1/d
 }
 
 // Canonical Moller-Trumbore on one 48-byte packet (see oracle tri_test): two-sided, division-free
@@ -237,14 +241,13 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
     d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
     sid = i * (uint32_t)(f.rows * f.width) + ly * (uint32_t)f.width + x;
     const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
-    const F3 id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-    const Bvh4Node* root = sc.nodes4 + sc.tlas_root4;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const Bvh4Child& c = root->c[k];
-      float tn;
-      survive = survive || slab(c.lo[0], c.lo[1], c.lo[2], c.hix, c.hiy, c.hiz, o, id, 0.001f, 10000.0f, tn);
-    }
+    F3 qs, qb; uint3 rot;
+    quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
+    const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
+    const uint4 Q0 = rp[0], Q1 = rp[1];
+    float tn;
+    survive = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
+    survive = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) || survive;
     if (!survive) {
       const F3 c = sample_sky(sc, mk3(d.x, d.y, -d.z));
       f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -306,13 +309,16 @@ constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both
 #ifndef RT_INTERIOR_UNROLL
 #define RT_INTERIOR_UNROLL 2
 #endif
+#ifndef RT_WIDE_UNROLL
+#define RT_WIDE_UNROLL 1
+#endif
 #ifndef RT_STACK2_LDS
 #define RT_STACK2_LDS 12   /* 12 entries in LDS (3 KB per wave) let 6 blocks share a CU; deeper paths spill to HBM */
 #endif
 constexpr int STACK2_LDS = RT_STACK2_LDS;
 constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 
-template <int MODE, bool ANY, bool COUNT>
+template <int MODE, bool ANY, bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   __shared__ int s_stack[4][STACK2_LDS][64];
   __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   }
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   int* const stk = &s_stack[wave][0][lane];                 // entry e at stk[e * 64]
-  int32_t* const ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * STACK_OVF;
+  int32_t* const ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * a.sc.ovf_stride;
   uint64_t cnt_nodes = 0, cnt_tris = 0, diag_iters = 0, diag_busy = 0;
   const uint64_t diag_t0 = COUNT ? __builtin_readcyclecounter() : 0;
 
@@ -382,10 +388,12 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   uint32_t q = 0, sid = 0;
   float tmin = 0.f, tmax = 0.f;
   F3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), co = wo, cd = wd, qs = mk3(1, 1, 1), qb = mk3(0, 0, 0);
+  uint3 rot = make_uint3(0u, 0u, 0u);
   float4 shc = make_float4(0, 0, 0, 0);
   float best_t = 0.f, best_u = 0.f, best_v = 0.f;
   int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
-  const char* const node_bytes = reinterpret_cast<const char*>(a.sc.blas_nodes);   // BLAS nodes, then the TLAS nodes
+  // BLAS nodes, then the TLAS nodes (WIDE: the 64-byte 4-ary records with the same numbering)
+  const char* const node_bytes = WIDE ? reinterpret_cast<const char*>(a.sc.wide_nodes) : reinterpret_cast<const char*>(a.sc.blas_nodes);
 
   auto push = [&](int v) {
     if (sp < STACK2_LDS) stk[sp * 64] = v;
@@ -416,7 +424,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
           else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
           wo = mk3(ro.x, ro.y, ro.z); wd = mk3(rd.x, rd.y, rd.z);
           co = wo; cd = wd;
-          quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
+          quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
           best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
           cur_inst = -1;
           stk[0] = REF_DONE; sp = 1;
@@ -432,14 +440,70 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
     // ---- (B) interior-node loop: runs while most live lanes are at interior nodes.  The exit vote (ballot, popcount,
     // compare) is taken every RT_INTERIOR_UNROLL trips; in between, lanes that left the interior state just idle.
     auto interior_step = [&]() {
+      if (WIDE) {
+        if (cur >= 0) {
+          const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 6));   // 64-byte record: four requests
+          const uint4 X = np[0], Y = np[1], Z = np[2], R = np[3];
+          if (COUNT) cnt_nodes++;
+          float t0, t1, t2, t3;
+          const bool h0 = slab_q(X.x, Y.x, Z.x, qs, qb, rot, tmin, best_t, t0);
+          const bool h1 = slab_q(X.y, Y.y, Z.y, qs, qb, rot, tmin, best_t, t1);
+          const bool h2 = slab_q(X.z, Y.z, Z.z, qs, qb, rot, tmin, best_t, t2);
+          const bool h3 = slab_q(X.w, Y.w, Z.w, qs, qb, rot, tmin, best_t, t3);
+          // entry distance with the entry number in its two low mantissa bits; a miss sorts last
+          uint32_t k0 = h0 ? (__float_as_uint(t0) & ~3u) : 0xFFFFFFFFu;
+          uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFFu;
+          uint32_t k2 = h2 ? ((__float_as_uint(t2) & ~3u) | 2u) : 0xFFFFFFFFu;
+          uint32_t k3 = h3 ? ((__float_as_uint(t3) & ~3u) | 3u) : 0xFFFFFFFFu;
+          const int nh = (int)h0 + (int)h1 + (int)h2 + (int)h3;
+#define RT_CAS(a_, b_) { const uint32_t lo_ = min(a_, b_), hi_ = max(a_, b_); a_ = lo_; b_ = hi_; }
+          RT_CAS(k0, k1) RT_CAS(k2, k3) RT_CAS(k0, k2) RT_CAS(k1, k3) RT_CAS(k1, k2)
+#undef RT_CAS
+          auto link = [&](uint32_t key) -> int {
+            const uint32_t e = key & 3u;
+            return (int)(e == 0u ? R.x : e == 1u ? R.y : e == 2u ? R.z : R.w);
+          };
+          if (nh == 0) pop();
+          else {
+            if (nh > 1) {   // far entries first, so the nearest of them is popped first
+              if (nh > 2) {
+                if (nh > 3) push(link(k3));
+                push(link(k2));
+              }
+              push(link(k1));
+            }
+            cur = link(k0);
+          }
+        }
+        return;
+      }
       if (cur >= 0) {   // idle lanes hold REF_DONE
         const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
-        const uint4 Q0 = np[0], Q1 = np[1];
+        uint4 Q0 = np[0], Q1 = np[1];
+#ifdef RT_EXP_DUP_LOADS   // sensitivity experiment: the same lines fetched again (L1 hits, address-unit load only)
+        {
+          const uint32_t z = a.shard_cap >> 31;   // 0 at run time, opaque to the compiler
+#pragma unroll
+          for (int e = 1; e <= RT_EXP_DUP_LOADS; e++) {
+            const uint4* dp = np + (size_t)z * 2u * e;
+            const uint4 D0 = dp[0], D1 = dp[1];
+            Q0.x |= D0.x & z; Q1.x |= D1.x & z;
+          }
+        }
+#endif
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
-        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, tmin, best_t, t0);
-        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, tmin, best_t, t1);
+        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, tmin, best_t, t0);
+        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, tmin, best_t, t1);
+#ifdef RT_EXP_EXTRA_VALU   // sensitivity experiment: a dependent chain of extra fmas per visit
+        {
+          float acc = t0;
+#pragma unroll
+          for (int e = 0; e < RT_EXP_EXTRA_VALU; e++) acc = __builtin_fmaf(acc, qs.x, qb.y);
+          if (acc == 12345.678f) t1 = t0;
+        }
+#endif
         if (h0 && h1) {
           const bool swap = t1 < t0;
           push(swap ? ch.x : ch.y);
@@ -449,13 +513,21 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
         else pop();
       }
     };
+#ifdef RT_EXP_PHASE_DIAG   // experiment: diag = (outer passes, cycles inside the interior loop, wave cycles)
+    const uint64_t ph_t0 = COUNT ? __builtin_readcyclecounter() : 0;
+#endif
     for (;;) {
       const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(cur >= 0));
       if (n_int == 0 || n_int < keep_going) break;
+#ifndef RT_EXP_PHASE_DIAG
       if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
+#endif
 #pragma unroll
-      for (int r = 0; r < RT_INTERIOR_UNROLL; r++) interior_step();
+      for (int r = 0; r < (WIDE ? RT_WIDE_UNROLL : RT_INTERIOR_UNROLL); r++) interior_step();
     }
+#ifdef RT_EXP_PHASE_DIAG
+    if (COUNT && lane == 0) { diag_iters++; diag_busy += __builtin_readcyclecounter() - ph_t0; }
+#endif
 
     // ---- (C) the rarer bodies, each run once for all lanes that wait at them.  They are chained (leaf, then
     // leave-instance, then enter-instance) so that a lane can finish a leaf, leave its instance and enter the
@@ -482,7 +554,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
     if (cur == REF_MARK) {
       // leave the instance: back to the world-space ray and the TLAS
       co = wo; cd = wd;
-      quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb);
+      quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
       cur_inst = -1;
       pop();
     }
@@ -498,7 +570,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
         m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
         m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
         co = xform_point(m, wo); cd = xform_vec(m, wd);
-        quant_space(co, cd, I->q_lo, I->q_scale, qs, qb);
+        quant_space(co, cd, I->q_lo, I->q_scale, qs, qb, rot);
         push(REF_MARK);
         cur_inst = ii; cur = I->blas_root;
       }
@@ -1010,8 +1082,11 @@ static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& 
   a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
   const dim3 g(cfg.trace_blocks), b(256);
   if (cfg.variant == 0) {
-    if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE, ANY, false>), g, b, 0, s, a);
+    if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE, ANY, false, false>), g, b, 0, s, a);
+  } else if (cfg.variant == 2) {
+    if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE, ANY, false, true>), g, b, 0, s, a);
   } else {
     if (counting) hipLaunchKernelGGL((k_trace4<MODE, ANY, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace4<MODE, ANY, false>), g, b, 0, s, a);

@@ -41,6 +41,7 @@ struct Mesh {
   std::vector<BvhNodeQ> qnodes;   // quantized form of bvh.nodes
   float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
   std::vector<TriPacket> tris;
+  int levels = 0;                 // interior levels of the BVH2 (bounds the traversal stack)
   int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays
   uint32_t tri_base = 0;
 };
@@ -68,6 +69,9 @@ struct rt_ctx {
   Bvh4Node* d_nodes4 = nullptr;     // BLAS BVH4 nodes followed by the TLAS BVH4 nodes
   size_t cap_nodes4 = 0, n_blas4 = 0;
   std::vector<Bvh4Node> h_blas4;
+  WideNodeQ* d_wide = nullptr;      // 4-ary records of the same trees, same numbering as d_blas_nodes
+  std::vector<WideNodeQ> h_wide;
+  uint32_t ovf_stride = STACK_OVF, ovf_alloc_stride = 0;
   float4* d_tris = nullptr;
   size_t n_blas_nodes = 0, n_tris = 0;
 
@@ -199,7 +203,15 @@ int link_blas(rt_ctx* c) {
       nodes4[m.node_base4 + i] = n;
     }
     if (!m.tris.empty()) memcpy(&tris[m.tri_base], m.tris.data(), m.tris.size() * sizeof(TriPacket));
+    m.levels = bvh2_levels(m.qnodes.data(), m.qnodes.size(), 0);
+    if (m.levels < 0) return fail(c, RT_ERR_DEVICE, "BLAS builder produced a node graph that is not a tree");
   }
+  std::vector<WideNodeQ> wide(c->cfg.variant == 2 ? nn : 0);   // only the variant that walks them pays for them
+  if (c->cfg.variant == 2)
+    for (auto& m : c->meshes)
+      if (m.built && !m.qnodes.empty()) widen_bvh2(&nodes[m.node_base], m.qnodes.size(), m.node_base, &wide[m.node_base]);
+  c->h_wide.swap(wide);
+  if (c->d_wide) { HIP_TRY(c, hipFree(c->d_wide)); c->d_wide = nullptr; }
   if (c->d_blas_nodes) { HIP_TRY(c, hipFree(c->d_blas_nodes)); c->d_blas_nodes = nullptr; c->cap_nodesq = 0; }
   if (c->d_tris) { HIP_TRY(c, hipFree(c->d_tris)); c->d_tris = nullptr; }
   if (c->d_nodes4) { HIP_TRY(c, hipFree(c->d_nodes4)); c->d_nodes4 = nullptr; c->cap_nodes4 = 0; }
@@ -225,6 +237,11 @@ int upload_instances(rt_ctx* c) {
     c->cap_nodesq = needq + 64;
     HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, c->cap_nodesq * sizeof(BvhNodeQ)));
     if (c->n_blas_nodes) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, c->h_blasq.data(), c->n_blas_nodes * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
+    if (c->d_wide) { HIP_TRY(c, hipFree(c->d_wide)); c->d_wide = nullptr; }
+  }
+  if (!c->d_wide && c->cfg.variant == 2) {
+    HIP_TRY(c, hipMalloc((void**)&c->d_wide, c->cap_nodesq * sizeof(WideNodeQ)));
+    if (c->n_blas_nodes) HIP_TRY(c, hipMemcpy(c->d_wide, c->h_wide.data(), c->n_blas_nodes * sizeof(WideNodeQ), hipMemcpyHostToDevice));
   }
   // stream-ordered so a per-frame update never stalls the host on a fence (the reference blocks on
   // vkWaitForFences every frame, src/main.cpp:772-778)
@@ -249,6 +266,11 @@ int upload_instances(rt_ctx* c) {
     if (nd.child1 >= 0) nd.child1 += (int32_t)c->n_blas_nodes;
   }
   HIP_TRY(c, hipMemcpyAsync(c->d_blas_nodes + c->n_blas_nodes, tq.data(), tq.size() * sizeof(BvhNodeQ), hipMemcpyHostToDevice, c->stream));
+  std::vector<WideNodeQ> tw(c->cfg.variant == 2 ? tq.size() : 0);
+  if (c->cfg.variant == 2) {
+    widen_bvh2(tq.data(), tq.size(), (int32_t)c->n_blas_nodes, tw.data());
+    HIP_TRY(c, hipMemcpyAsync(c->d_wide + c->n_blas_nodes, tw.data(), tw.size() * sizeof(WideNodeQ), hipMemcpyHostToDevice, c->stream));
+  }
   HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rewritten by the next call
   return RT_OK;
 }
@@ -256,6 +278,7 @@ int upload_instances(rt_ctx* c) {
 SceneDev scene_dev(const rt_ctx* c) {
   SceneDev s{};
   s.nodes4 = c->d_nodes4; s.tlas_root4 = (int)c->n_blas4;
+  s.wide_nodes = c->d_wide; s.ovf_stride = c->ovf_stride;
   s.blas_nodes = c->d_blas_nodes; s.tlas_root = (int)c->n_blas_nodes; s.tris = c->d_tris; s.inst = c->d_inst;
   s.verts = c->d_verts; s.idx = c->d_idx; s.sky = c->d_sky; s.n_inst = (int)c->h_inst_dev.size();
   s.sky_w = c->sky_w; s.sky_h = c->sky_h;
@@ -272,7 +295,11 @@ int ready_to_trace(rt_ctx* c) {
 
 int ensure_common(rt_ctx* c) {
   if (!c->d_counters) HIP_TRY(c, hipMalloc((void**)&c->d_counters, CNT_WORDS * sizeof(uint32_t)));
-  if (!c->d_ovf) HIP_TRY(c, hipMalloc((void**)&c->d_ovf, (size_t)c->cfg.trace_blocks * 256 * STACK_OVF * sizeof(int32_t)));
+  if (c->d_ovf && c->ovf_alloc_stride < c->ovf_stride) { HIP_TRY(c, hipFree(c->d_ovf)); c->d_ovf = nullptr; }
+  if (!c->d_ovf) {
+    HIP_TRY(c, hipMalloc((void**)&c->d_ovf, (size_t)c->cfg.trace_blocks * 256 * c->ovf_stride * sizeof(int32_t)));
+    c->ovf_alloc_stride = c->ovf_stride;
+  }
   return RT_OK;
 }
 
@@ -376,7 +403,7 @@ int collect_stats(rt_ctx* c) {
   memcpy(&st.tri_tests_shadow, &cnt[CNT_TRI_TESTS_SH], 8);
   memcpy(&st.diag[0], &cnt[CNT_DIAG], 24);
   memcpy(&st.diag[3], &cnt[CNT_DIAG_SH], 24);
-  st.bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNodeQ); st.bvh_tri_bytes = sizeof(TriPacket);
+  st.bvh_node_bytes = c->cfg.variant == 1 ? sizeof(Bvh4Node) : c->cfg.variant == 2 ? sizeof(WideNodeQ) : sizeof(BvhNodeQ); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, sp.a, sp.b) != hipSuccess) continue;
@@ -435,7 +462,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
   if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
-  if (const char* env = getenv("RT_TRACE_VARIANT")) c->cfg.variant = atoi(env) ? 1 : 0;
+  if (const char* env = getenv("RT_TRACE_VARIANT")) { const int v = atoi(env); c->cfg.variant = (v >= 0 && v <= 2) ? v : 0; }
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   *out_ctx = c;
   return RT_OK;
@@ -446,7 +473,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
+  void* ptrs[] = {c->d_wide, c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   for (auto e : c->ev_pool) hipEventDestroy(e);
@@ -491,7 +518,7 @@ int rt_build_blas(rt_ctx* c, int mesh) {
   if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
   Mesh& m = c->meshes[mesh];
   m.gpu_built = false;
-  if (c->blas_builder == 1 && c->cfg.variant == 0 && m.range.prim_count >= 8) {
+  if (c->blas_builder == 1 && c->cfg.variant != 1 && m.range.prim_count >= 8) {
     // device build: LBVH straight from the uploaded vertex/index buffers; the result is downloaded once so that the
     // linker treats every mesh alike
     HIP_TRY(c, hipSetDevice(c->device));
@@ -548,11 +575,19 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
   else { build_bvh(boxes.data(), (uint32_t)n, 1, 20, c->tlas); collapse_bvh4(c->tlas, false, true, c->tlas4); }
   // the quad traversal keeps its whole stack in LDS: bottom sentinel + TLAS + marker + deepest BLAS
-  int blas_need = 0;
+  int blas_need = 0, blas_levels = 0;
   for (int i = 0; i < n; i++) {
     const Mesh& m = c->meshes[inst[i].mesh];
-    if (m.gpu_built && c->cfg.variant == 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "device-built BLAS is traversed by trace_variant 0 only: set trace_variant before rt_build_blas or use blas_builder 0");
+    if (m.gpu_built && c->cfg.variant == 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "device-built BLAS is not traversed by trace_variant 1: set trace_variant before rt_build_blas or use blas_builder 0");
     blas_need = std::max(blas_need, m.bvh4.stack_need);
+    blas_levels = std::max(blas_levels, m.levels);
+  }
+  {
+    // one-lane kernels: bottom sentinel + TLAS + leave-instance marker + deepest BLAS; the 4-ary records push up
+    // to three links per two BVH2 levels.  Whatever exceeds the LDS part of the stack spills to ovf_stride entries.
+    const int tl = c->tlas.depth + 1;
+    const int need2 = 2 + tl + blas_levels, needw = 2 + 3 * ((tl + 1) / 2) + 3 * ((blas_levels + 1) / 2);
+    c->ovf_stride = (uint32_t)std::max<int>(STACK_OVF, (std::max(need2, needw) + 7) & ~7);
   }
   if (1 + c->tlas4.stack_need + 1 + blas_need > STACK4_LDS)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
@@ -595,8 +630,14 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (!c || !name) return RT_ERR_INVALID_ARGUMENT;
   std::string k(name);
   if (k == "trace_variant") {
-    if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0 or 1");
+    if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0, 1 or 2");
+    const int before = c->cfg.variant;
     c->cfg.variant = value;
+    if (value == 2 && before != 2 && c->blas_linked) {
+      // the 4-ary records are derived from the linked BVH2 on demand
+      c->blas_linked = false;
+      if (c->tlas_valid) { std::vector<rt_instance> keep = c->h_inst; c->tlas_valid = false; return rt_set_instances(c, keep.data(), (int)keep.size(), 0); }
+    }
     if (value == 1) {
       // the quad kernel walks the BVH4 that only the host builder produces: rebuild device-built meshes on the host
       bool rebuilt = false;
@@ -794,7 +835,7 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     if (any_hit) stats->ms_trace_shadow = ms; else stats->ms_trace_closest = ms;
     stats->closest_rays = any_hit ? 0 : n; stats->rays_shadow = any_hit ? n : 0;
-    stats->bvh_node_bytes = c->cfg.variant ? sizeof(Bvh4Node) : sizeof(BvhNodeQ); stats->bvh_tri_bytes = sizeof(TriPacket);
+    stats->bvh_node_bytes = c->cfg.variant == 1 ? sizeof(Bvh4Node) : c->cfg.variant == 2 ? sizeof(WideNodeQ) : sizeof(BvhNodeQ); stats->bvh_tri_bytes = sizeof(TriPacket);
   }
   hipEventDestroy(e0); hipEventDestroy(e1);
   hipFree(d_o); hipFree(d_d); hipFree(d_h);

@@ -36,6 +36,19 @@ struct alignas(16) BvhNodeQ {
 };
 static_assert(sizeof(BvhNodeQ) == 32, "BvhNodeQ must be 32 bytes");
 
+// Wide (4-ary) view of the same tree, 64 B: record i holds the GRANDCHILDREN of BVH2 node i (a child that
+// is a leaf stays as it is), in the same fixed-point space and with the same node numbering, so roots and
+// links are shared with the BvhNodeQ array.  One visit tests four boxes: half as many dependent node
+// fetches per ray, and the per-visit overhead (address, loop vote, stack) is paid once per four boxes.
+// Axis-major so that a lane reads four dwordx4: x[k] = lo.x | hi.x << 16 of entry k, ...; an unused entry
+// is the point box at quantum 0 with the link of entry 0 (a ray through that very point repeats entry 0,
+// which is harmless: the tie rule makes triangle tests idempotent).
+struct alignas(16) WideNodeQ {
+  uint32_t x[4], y[4], z[4];
+  int32_t ref[4];
+};
+static_assert(sizeof(WideNodeQ) == 64, "WideNodeQ must be 64 bytes");
+
 // BVH4 node for the quad-cooperative traversal (4 lanes per ray): 128 B = one cache line, child k at
 // byte 32k so that the 4 lanes of a quad read 4 consecutive 32-byte records (2 x dwordx4 each).
 //   (lo.x, lo.y, lo.z, hi.x) (hi.y, hi.z, ref, 0);  ref as in BvhNode::child*; a missing child is the
@@ -123,7 +136,7 @@ constexpr uint32_t SID_DEAD = 0xFFFFFFFFu;   // padding lane of the primary queu
 constexpr int STACK4_LDS = 64;               // quad kernel: stack entries per RAY, all in LDS; the builder
                                              // verifies the worst case of every tree against it
 constexpr int STACK_LDS = 24;                // per-lane traversal stack entries kept in LDS
-constexpr int STACK_OVF = 40;                // spill entries per lane in HBM (never touched by sane trees)
+constexpr int STACK_OVF = 40;                // smallest spill area per lane in HBM (rt_api sizes it from the tree depth)
 constexpr int BLAS_MAX_DEPTH = 40;           // builder-enforced; TLAS <= 20; + 1 return marker <= 64
 
 }  // namespace rt

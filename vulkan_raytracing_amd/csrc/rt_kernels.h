@@ -12,6 +12,7 @@ struct SceneDev {
   int tlas_root;               // index of the TLAS root in blas_nodes
   const float4* tris;          // 3 float4 per TriPacket
   float tlas_q_lo[3], tlas_q_scale[3];
+  const WideNodeQ* wide_nodes; // variant 2: 4-ary records, same numbering as blas_nodes
   const Bvh4Node* nodes4;      // quad traversal (variant 1): BLAS BVH4 nodes, then the TLAS BVH4 nodes
   int tlas_root4;              // index of the TLAS root in nodes4
   const InstanceDev* inst;
@@ -20,6 +21,7 @@ struct SceneDev {
   const uchar4* sky;           // binding 5: 6 layers RGBA8
   int n_inst;
   int sky_w, sky_h;
+  uint32_t ovf_stride;         // spill entries per lane behind the LDS stack, sized from the depth of the trees
 };
 
 struct FrameDev {
@@ -32,7 +34,7 @@ struct FrameDev {
   float4* sh_c;                //               (diffuse+specular rgb, 0.9^i)
   float4* sample_color;        // per-sample tmpColor (rgb, 1), index = i*(rows*W) + ly*W + x
   uint32_t* counters;          // rt::CNT_* layout
-  int32_t* ovf_stack;          // STACK_OVF ints per persistent thread
+  int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread
   float4* out;                 // compact shard image (rows x W RGBA32F)
   uint32_t shard_cap;          // entries per queue shard (queues hold N_SHARDS * shard_cap rays)
   int width, height;           // full frame
@@ -45,7 +47,7 @@ struct LaunchCfg {
   int shade_blocks;
   int rays_per_lane;           // device-side grid sizing of the traversal kernels (see k_trace)
   int min_blocks;
-  int variant;                 // 0: BVH2, one lane per ray; 1: BVH4, four lanes per ray (default)
+  int variant;                 // 0: BVH2, one lane per ray; 1: BVH4, four lanes per ray; 2: 4-ary records, one lane per ray
 };
 
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
