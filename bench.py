@@ -6,8 +6,10 @@ supplied) + skybox_texture_sea, 1920x1080, depth 4 (maxBounceCount 3) + shadow r
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU, --frames-in-flight (3) independent frames in flight per GPU (the reference's swapchain
-keeps minImageCount + 1 frames in flight, src/main.cpp:1203, 2967).  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
+One process per GPU, --frames-in-flight (4) independent frames in flight per GPU (the reference's swapchain keeps
+minImageCount + 1 frames in flight, src/main.cpp:1203, 2967), each on its own HIP stream — one per hardware queue of
+the HIP default (GPU_MAX_HW_QUEUES=4; 8 queues with 8 frames measured 13 % faster on a 1/8 shard but 13 % slower
+with 4 frames, so the default stays).  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
 x 4 bounces -> any-hit shadow traversal -> resolve, on this rank's interleaved 8-row bands, followed
 (N > 1) by ONE RCCL gather of the compact shards to rank 0 and the row permutation that reassembles
 the frame.  The frame is fixed, so scaling is STRONG.  Inputs (scene, BVH, cube map) are resident in
@@ -114,10 +116,10 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames in flight per GPU, each on its own stream and buffers; the reference keeps "
                          "swapchainImageCount = minImageCount + 1 frames in flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: "
-                         "3 on one GPU, 4 when the frame is split over several (a 1/N shard is latency-bound, one more frame hides it)")
+                         "4, one per HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
-    ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray")
+    ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray; 2 = 4-ary records, one lane per ray")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
                     help="cfg3 (default, the headline): 1920x1080 depth 4; cfg4: 3840x2160 depth 6; cfg5: 16 instances of the armadillo BLAS, 1920x1080 depth 4")
@@ -162,7 +164,7 @@ def main():
     n = world
     collective = n > 1 or args.force_collective
     assert args.gpus == n, "--gpus must equal the number of launched ranks"
-    P = args.frames_in_flight if args.frames_in_flight > 0 else (3 if n == 1 else 4)
+    P = args.frames_in_flight if args.frames_in_flight > 0 else 4
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
@@ -230,6 +232,11 @@ def main():
             torch.cuda.synchronize(dev)
 
     ctx.set_timing(True)   # HIP events around every kernel of context 0's frames (every P-th frame), on their own stream
+    # set-up, not a step: one frame per context so that every context has its ray queues allocated before the
+    # warm-up/timed steps start (a context allocates them on its first frame)
+    for _ in range(P):
+        step()
+    sync()
     for _ in range(args.warmup):
         step()
     sync()

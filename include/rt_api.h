@@ -152,7 +152,9 @@ int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
 int rt_set_timing(rt_ctx* ctx, int enabled);
 
 /* Tunables (no reference counterpart): "trace_variant" 0 = quantized BVH2 / one lane per ray (default), 1 = BVH4 /
- * four lanes per ray; "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device LBVH (default:
+ * four lanes per ray, 2 = 4-ary records / one lane per ray; "tail_kernel" 0 = one launch per bounce and kernel, 1 = bounces
+ * 1..maxBounceCount in one launch when the previous frame had few secondary rays (default), 2 = always;
+ * "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device LBVH (default:
  * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357), 0 = host binned-SAH;
  * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids.  Results do not depend on any of them. */
 int rt_set_param(rt_ctx* ctx, const char* name, int value);

@@ -347,14 +347,25 @@ def test_device_built_blas_gives_identical_results(ctx, algo, monkeypatch):
 
 def test_reference_default_bounce_budget_63(ctx):
     """The reference's own defaults: MAX_BOUNCE_COUNT 63 (include/config.h:26) with a refractive and a mirror object —
-    exercises deep bounce queues and the host-side early exit once every path has ended."""
+    exercises deep bounce queues, the host-side early exit of the per-bounce launches and the one-launch k_tail path."""
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 2, 1, 63, 2,
                                  sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.8)
     W, H = 160, 96
-    gpu, st = ctx.trace(W, H)
     ref, rc = sp.orc.render(W, H)
-    check_image(gpu, ref)
-    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    imgs = {}
+    try:
+        # 0: one launch per bounce and kernel (with host polls), 2: bounces 1..63 inside one k_tail launch,
+        # 1: the default (k_tail once a previous frame reported few secondary rays)
+        for mode in (0, 2, 1):
+            ctx.set_param("tail_kernel", mode)
+            for _ in range(2):
+                gpu, st = ctx.trace(W, H)
+            check_image(gpu, ref)
+            assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+            imgs[mode] = (gpu, st.launches_total)
+    finally:
+        ctx.set_param("tail_kernel", 1)
+    assert np.array_equal(imgs[0][0], imgs[2][0]) and np.array_equal(imgs[0][0], imgs[1][0])
     assert st.rays_secondary > st.rays_primary // 50
 
 

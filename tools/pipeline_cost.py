@@ -15,15 +15,19 @@ from vulkan_raytracing_amd import RtContext, tiling  # noqa: E402
 def main():
     W, H, band = bench.WIDTH, bench.HEIGHT, tiling.BAND_ROWS
     ctxs = []
-    for _ in range(4):
+    params = [kv.split("=") for kv in os.environ.get("RT_PARAMS", "").split(",") if kv]   # e.g. RT_PARAMS=tail_kernel=0,trace_rays_per_lane=2
+    for _ in range(int(os.environ.get("N_CTX", "8"))):
         c = RtContext(0)
         bench.build_scene(c, os.path.join(ROOT, "resources"))
+        for k, v in params:
+            c.set_param(k, int(v))
         ctxs.append(c)
+    print("params", params, flush=True)
     streams = [torch.cuda.Stream() for _ in ctxs]
     for n in (1, 8):
         rows = tiling.max_shard_rows(H, band, n)
         bufs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda:0") for _ in ctxs]
-        for P in (1, 2, 3, 4):
+        for P in [int(x) for x in os.environ.get("P_LIST", "1,2,3,4,6,8").split(",")]:
             K = 60
             for phase in range(2):
                 torch.cuda.synchronize()

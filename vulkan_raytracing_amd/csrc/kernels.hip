@@ -120,6 +120,11 @@ __device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter) {
   return base + prefix_rank(mask);
 }
 
+// Queue cursors are read with agent scope: inside k_tail a queue is filled by other workgroups of the same launch.
+__device__ __forceinline__ uint32_t ld_cursor(const uint32_t* p) {
+  return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ float safe_rcp(float d) {
   const float eps = 1e-20f;
   float a = __builtin_fabsf(d) < eps ? __builtin_copysignf(eps, d) : d;
@@ -281,6 +286,7 @@ struct TraceArgs {
   float tmin;
   uint32_t rays_per_lane;      // device-side grid sizing (variant 0): blocks beyond total/(256*rays_per_lane) exit
   uint32_t min_blocks;
+  uint32_t* hint;              // host-mapped word that receives the queue size (bounce 1 only; NULL otherwise)
 };
 
 constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
@@ -319,7 +325,7 @@ constexpr int STACK2_LDS = RT_STACK2_LDS;
 constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 
 template <int MODE, bool ANY, bool COUNT, bool WIDE>
-__global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
+__device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS][64];
   __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];
   __shared__ float4 s_out[4][64];
@@ -330,7 +336,8 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   {
     uint32_t total = 0;
 #pragma unroll
-    for (int t = 0; t < N_SHARDS; t++) total += a.tails[t * CNT_STRIDE];
+    for (int t = 0; t < N_SHARDS; t++) total += ld_cursor(a.tails + t * CNT_STRIDE);
+    if (a.hint && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t want = (total + 256u * a.rays_per_lane - 1u) / (256u * a.rays_per_lane);
     want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
     if (want < a.min_blocks) want = a.min_blocks;
@@ -350,7 +357,7 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   auto prefetch = [&]() {
     pf_count = 0;
     while (tried < (uint32_t)N_SHARDS) {
-      const uint32_t size = a.tails[shard * CNT_STRIDE];
+      const uint32_t size = ld_cursor(a.tails + shard * CNT_STRIDE);
       uint32_t off = 0;
       if (lane == 0 && size) off = atomicAdd(a.work + shard * CNT_STRIDE, 64u);
       off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
@@ -616,7 +623,10 @@ __global__ __launch_bounds__(256) void k_trace(TraceArgs a) {
   }
 }
 
-// ---- variant 1 (default): quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
+template <int MODE, bool ANY, bool COUNT, bool WIDE>
+__global__ __launch_bounds__(256) void k_trace(TraceArgs a) { trace_body<MODE, ANY, COUNT, WIDE>(a); }
+
+// ---- variant 1: quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
 // 64-lane wavefront.
 //   * interior node (128 B, one cache line): lane k of the quad loads and tests child k (2 x dwordx4
 //     per lane, 4 consecutive 32-byte records per quad): one line look-up per ray and visit, and
@@ -922,14 +932,14 @@ struct ShadeArgs {
   int bounce;
 };
 
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
+__device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   const FrameDev& f = a.f;
   const UniformsDev& U = a.u;
   const int cur = a.bounce & 1, nxt = cur ^ 1;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   uint32_t cnt[N_SHARDS], maxb = 0;
 #pragma unroll
-  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = f.counters[cnt_tail(a.bounce, t)]; maxb = max(maxb, (cnt[t] + 63u) >> 6); }
+  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = ld_cursor(f.counters + cnt_tail(a.bounce, t)); maxb = max(maxb, (cnt[t] + 63u) >> 6); }
   const uint32_t n_waves = gridDim.x * 4u;
   for (uint32_t g = blockIdx.x * 4u + wave; g < maxb * N_SHARDS; g += n_waves) {
     const uint32_t shard = g & (N_SHARDS - 1), base = (g >> 3) << 6;
@@ -1038,6 +1048,66 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) {
   }
 }
 
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body(a); }
+
+// ------------------------------------------------------------------------------------------------
+// k_tail: bounces first..maxBounceCount of one frame in ONE launch.  After the first bounce a frame usually
+// has few live paths (mirror / glass pixels only) but the loop of src/shader.rgen:84 may run up to 63 more
+// times; one launch per bounce and kernel would be 2 x 63 nearly empty launches (or host polls).  Here a
+// small persistent grid alternates traversal and shading, separated by a grid-wide barrier, and leaves as
+// soon as a bounce queue is empty — the same test the reference loop makes per pixel.  The grid is small
+// (TAIL_BLOCKS) so that the tails of every frame in flight are co-resident and a barrier can always complete;
+// a frame with many secondary rays takes the per-bounce launches instead (rt_api decides from the last frame).
+struct TailArgs {
+  TraceArgs tr;          // closest-hit arguments; ray queue / cursors are set per bounce
+  ShadeArgs sh;
+  uint32_t first_bounce;
+  uint32_t* barrier;     // counters + CNT_BARRIER (zeroed with the counters at frame start)
+  uint32_t* fault;       // counters + CNT_FAULT: set when a barrier gave up
+};
+
+__device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t* fault, uint32_t& phase) {
+  __syncthreads();
+  phase++;
+  if (threadIdx.x == 0) {
+    __threadfence();                                   // release this workgroup's queue writes
+    const uint32_t target = phase * gridDim.x;
+    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 24)) { __hip_atomic_store(fault, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }   // never hang the device
+    }
+    __threadfence();                                   // acquire the other workgroups' writes
+  }
+  __syncthreads();
+}
+
+template <bool COUNT, bool WIDE>
+__global__ __launch_bounds__(256) void k_tail(TailArgs t) {
+  uint32_t phase = 0;
+  const uint32_t max_bounce = t.sh.u.max_bounce_count;
+  for (uint32_t b = t.first_bounce; b <= max_bounce; b++) {
+    uint32_t live = 0;
+#pragma unroll
+    for (int k = 0; k < N_SHARDS; k++) live += ld_cursor(t.tr.counters + cnt_tail((int)b, k));
+    if (b == t.first_bounce && t.tr.hint && blockIdx.x == 0 && threadIdx.x == 0)
+      __hip_atomic_store(t.tr.hint, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (live == 0 || ld_cursor(t.fault) != 0u) break;   // uniform over the grid: the queue is final since the last barrier
+    TraceArgs a = t.tr;
+    a.hint = nullptr;
+    a.ray_o = t.sh.f.ray_o[b & 1u]; a.ray_d = t.sh.f.ray_d[b & 1u];
+    a.tails = t.tr.counters + cnt_tail((int)b, 0);
+    a.work = t.tr.counters + cnt_work((int)b, 0);
+    trace_body<MODE_CLOSEST, false, COUNT, WIDE>(a);
+    grid_barrier(t.barrier, t.fault, phase);
+    ShadeArgs sh = t.sh;
+    sh.bounce = (int)b;
+    shade_body(sh);
+    grid_barrier(t.barrier, t.fault, phase);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_resolve: src/shader.rgen:64,180-185 — ordered sum over samples, divide, store.
 __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
@@ -1095,6 +1165,7 @@ static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& 
 
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, f.counters, bounce, f.shard_cap, f.ovf_stack);
+  a.hint = bounce == 1 ? f.hint : nullptr;
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
@@ -1113,6 +1184,24 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
   a.ray_o = ray_o; a.ray_d = ray_d; a.raw_out = out;
   if (any_hit) launch_trace<MODE_RAW, true>(a, counting, cfg, s);
   else launch_trace<MODE_RAW, false>(a, counting, cfg, s);
+}
+
+void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+  TailArgs t{};
+  t.tr = make_args(sc, f.counters, first_bounce, f.shard_cap, f.ovf_stack);
+  t.tr.hit_a = f.hit_a; t.tr.hit_inst = f.hit_inst; t.tr.hint = f.hint;
+  t.tr.rays_per_lane = (uint32_t)cfg.rays_per_lane; t.tr.min_blocks = 8u;
+  t.sh = ShadeArgs{sc, f, u, first_bounce};
+  t.first_bounce = (uint32_t)first_bounce;
+  t.barrier = f.counters + CNT_BARRIER; t.fault = f.counters + CNT_FAULT;
+  const dim3 g(TAIL_BLOCKS), b(256);
+  if (cfg.variant == 2) {
+    if (counting) hipLaunchKernelGGL((k_tail<true, true>), g, b, 0, s, t);
+    else hipLaunchKernelGGL((k_tail<false, true>), g, b, 0, s, t);
+  } else {
+    if (counting) hipLaunchKernelGGL((k_tail<true, false>), g, b, 0, s, t);
+    else hipLaunchKernelGGL((k_tail<false, false>), g, b, 0, s, t);
+  }
 }
 
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s) {

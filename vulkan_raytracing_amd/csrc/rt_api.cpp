@@ -101,6 +101,9 @@ struct rt_ctx {
   uint32_t* d_counters = nullptr;
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
+  int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
+  uint32_t* h_hint = nullptr;    // pinned, device-visible word: size of bounce queue 1 in the most recent frame that reached
+  uint32_t* d_hint = nullptr;    // bounce 1 (written by the kernels; a speed hint only, never affects results)
   int blas_builder = 1;          // 1: device LBVH (bvh_gpu.hip, default), 0: host binned-SAH
   bool timing = false;
   bool counting = false;
@@ -295,6 +298,11 @@ int ready_to_trace(rt_ctx* c) {
 
 int ensure_common(rt_ctx* c) {
   if (!c->d_counters) HIP_TRY(c, hipMalloc((void**)&c->d_counters, CNT_WORDS * sizeof(uint32_t)));
+  if (!c->h_hint) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_hint, sizeof(uint32_t), hipHostMallocMapped));
+    *c->h_hint = 0xFFFFFFFFu;   // unknown: the first frame takes one launch per bounce
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_hint, c->h_hint, 0));
+  }
   if (c->d_ovf && c->ovf_alloc_stride < c->ovf_stride) { HIP_TRY(c, hipFree(c->d_ovf)); c->d_ovf = nullptr; }
   if (!c->d_ovf) {
     HIP_TRY(c, hipMalloc((void**)&c->d_ovf, (size_t)c->cfg.trace_blocks * 256 * c->ovf_stride * sizeof(int32_t)));
@@ -348,7 +356,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   const size_t capacity = shard_cap * N_SHARDS;
   int r = ensure_frame(c, capacity); if (r) return r;
   FrameDev f = c->frame;
-  f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out;
+  f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out; f.hint = c->d_hint;
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   const SceneDev sc = scene_dev(c);
@@ -364,7 +372,14 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     Span frame_span(c, CAT_FRAME, s);
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s));
     { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
+    const bool use_tail = c->cfg.variant != 1 && u.max_bounce_count >= 1 &&
+                          (c->tail_mode == 2 || (c->tail_mode == 1 && *(volatile uint32_t*)c->h_hint <= TAIL_MAX_RAYS));
     for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
+      if (b == 1 && use_tail) {
+        // every later bounce in one launch (src/shader.rgen:84 loop), leaving as soon as a queue is empty
+        Span sp(c, CAT_TRACE, s); launch_tail(sc, f, u, 1, c->counting, c->cfg, s);
+        break;
+      }
       { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
       { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
@@ -394,6 +409,8 @@ int collect_stats(rt_ctx* c) {
   st.rays_primary = c->last_primary;
   for (uint32_t b = 1; b <= c->last_max_bounce; b++) st.rays_secondary += queue_size((int)b);
   st.rays_shadow = queue_size(Q_SHADOW);
+  *c->h_hint = (uint32_t)std::min<uint64_t>(queue_size(1), 0xFFFFFFFFu);
+  if (cnt[CNT_FAULT] != 0) { c->frame_pending = false; return fail(c, RT_ERR_DEVICE, "k_tail: a grid barrier did not complete (frame discarded)"); }
   // rays that went through the closest-hit traversal kernel: primary rays that survived the TLAS-root
   // test fused into k_raygen (queue 0) plus every secondary ray
   st.closest_rays = queue_size(0) + st.rays_secondary;
@@ -476,6 +493,7 @@ void rt_destroy(rt_ctx* c) {
   void* ptrs[] = {c->d_wide, c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
+  if (c->h_hint) hipHostFree(c->h_hint);
   for (auto e : c->ev_pool) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -660,6 +678,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     if (c->d_ovf && value * c->n_cu > c->cfg.trace_blocks) { hipFree(c->d_ovf); c->d_ovf = nullptr; }
     c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
   }
+  if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); c->blas_builder = value; return RT_OK; }
   if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
   if (k == "trace_min_blocks") { if (value < 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_min_blocks must be >= 8"); c->cfg.min_blocks = value; return RT_OK; }

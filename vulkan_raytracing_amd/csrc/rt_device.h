@@ -117,6 +117,8 @@ constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: 
 constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounceCount <= 69)
 constexpr int Q_SHADOW = CNT_MAX_BOUNCES;      // queue id of the shadow-ray queue
 constexpr int N_QUEUES = CNT_MAX_BOUNCES + 1;
+constexpr int TAIL_BLOCKS = 64;                // grid of k_tail: small enough that the tails of all frames in flight are co-resident
+constexpr uint32_t TAIL_MAX_RAYS = 65536;      // frames whose first secondary queue is larger take one launch per bounce
 enum : int {
   CNT_NODE_VISITS = 0,     // uint64: closest-hit kernel (counting builds only)
   CNT_TRI_TESTS = 2,       // uint64
@@ -124,6 +126,8 @@ enum : int {
   CNT_TRI_TESTS_SH = 6,    // uint64
   CNT_DIAG = 8,            // 3 x uint64 (diagnostic counting build): loop trips, busy quad-trips, wave cycles
   CNT_DIAG_SH = 16,
+  CNT_BARRIER = 24,        // k_tail grid barrier (arrivals)
+  CNT_FAULT = 25,          // set by k_tail when a barrier gave up (reported as RT_ERR_DEVICE)
   CNT_TAILS = 32
 };
 constexpr int CNT_WORKS = CNT_TAILS + N_QUEUES * N_SHARDS * CNT_STRIDE;

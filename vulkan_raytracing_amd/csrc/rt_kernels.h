@@ -35,6 +35,7 @@ struct FrameDev {
   float4* sample_color;        // per-sample tmpColor (rgb, 1), index = i*(rows*W) + ly*W + x
   uint32_t* counters;          // rt::CNT_* layout
   int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread
+  uint32_t* hint;              // host-mapped word: size of bounce queue 1 (read by the host as a launch-strategy hint)
   float4* out;                 // compact shard image (rows x W RGBA32F)
   uint32_t shard_cap;          // entries per queue shard (queues hold N_SHARDS * shard_cap rays)
   int width, height;           // full frame
@@ -52,6 +53,8 @@ struct LaunchCfg {
 
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
+// bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
+void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
