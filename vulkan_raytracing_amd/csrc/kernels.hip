@@ -218,24 +218,23 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
 // into bounce queue 0 (shard blockIdx % 8) with a wavefront ballot.  On the headline frame ~80 % of
 // the primary rays end here, which removes their ray/hit records from HBM traffic altogether.
 __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u) {
-  const uint32_t tiles_x = ((uint32_t)f.width + 7u) >> 3;
-  const uint32_t tiles_y = ((uint32_t)f.rows + 7u) >> 3;
+  // grid (tiles_x, tiles_y, sample groups), block (64 lanes = one 8x8 tile, up to 4 samples): no index division
   const uint32_t spp = u.samples_per_pixel;
-  const uint32_t total = tiles_x * tiles_y * spp * 64u;
-  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t lane = t & 63u;
-  const uint32_t ts = t >> 6;
-  const uint32_t i = ts % spp;
-  const uint32_t tile = ts / spp;
-  const uint32_t x = (tile % tiles_x) * 8u + (lane & 7u);
-  const uint32_t ly = (tile / tiles_x) * 8u + (lane >> 3);
-  const bool live = t < total && x < (uint32_t)f.width && ly < (uint32_t)f.rows;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t i = blockIdx.z * blockDim.y + threadIdx.y;
+  const uint32_t x = blockIdx.x * 8u + (lane & 7u);
+  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  const bool live = i < spp && x < (uint32_t)f.width && ly < (uint32_t)f.rows;
   bool survive = false;
   F3 d = mk3(0.f, 0.f, 1.f);
   uint32_t sid = 0;
   if (live) {
-    const uint32_t band = ly / (uint32_t)f.band_rows;
-    const uint32_t y = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + (ly % (uint32_t)f.band_rows);
+    uint32_t y = ly;   // local row -> frame row of this shard's interleaved bands
+    if (f.n_shards != 1) {
+      const uint32_t band = f.band_rows == 8 ? blockIdx.y : ly / (uint32_t)f.band_rows;
+      const uint32_t within = f.band_rows == 8 ? (lane >> 3) : ly % (uint32_t)f.band_rows;
+      y = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + within;
+    }
     const float fx = (float)x, fy = (float)y;
     const float seed0 = (float)(spp + i), seed1 = seed0 + 0.5f;
     float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)f.width;
@@ -258,7 +257,8 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
     }
   }
-  const uint32_t shard = blockIdx.x & (N_SHARDS - 1);
+  // workgroups are handed to the XCDs round-robin in linear order
+  const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & (N_SHARDS - 1);
   const uint32_t slot = wave_alloc(survive, f.counters + cnt_tail(0, (int)shard));
   if (survive) {
     const uint32_t v = shard * f.shard_cap + slot;
@@ -1127,10 +1127,19 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
 // launchers
 int trace_threads_per_block() { return 256; }
 
+// k_raygen grid: one workgroup per (8x8 tile, group of up to 4 samples)
+static dim3 raygen_grid(int width, int rows, uint32_t spp, dim3& block) {
+  const uint32_t wpb = spp < 4u ? spp : 4u;
+  block = dim3(64, wpb);
+  return dim3(((uint32_t)width + 7u) >> 3, ((uint32_t)rows + 7u) >> 3, (spp + wpb - 1u) / wpb);
+}
+size_t raygen_block_count(int width, int rows, uint32_t spp) {
+  dim3 b; const dim3 g = raygen_grid(width, rows, spp, b);
+  return (size_t)g.x * g.y * g.z;
+}
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s) {
-  const uint32_t tiles = (((uint32_t)f.width + 7u) >> 3) * (((uint32_t)f.rows + 7u) >> 3);
-  const uint32_t total = tiles * u.samples_per_pixel * 64u;
-  hipLaunchKernelGGL(k_raygen, dim3((total + 255u) / 256u), dim3(256), 0, s, sc, f, u);
+  dim3 b; const dim3 g = raygen_grid(f.width, f.rows, u.samples_per_pixel, b);
+  hipLaunchKernelGGL(k_raygen, g, b, 0, s, sc, f, u);
 }
 
 static TraceArgs make_args(const SceneDev& sc, uint32_t* counters, int queue, uint32_t shard_cap, int32_t* ovf) {

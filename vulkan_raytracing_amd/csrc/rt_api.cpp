@@ -349,9 +349,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
   const size_t samples = tiles * u.samples_per_pixel * 64;   // k_raygen threads
   if (samples >= 0xF0000000ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for 32-bit sample ids");
+  if (rows > 8 * 65535 || u.samples_per_pixel > 4u * 65535u) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for the raygen grid");
   // k_raygen block b appends to shard b % 8, so a shard never receives more than this many rays; paths
   // stay in their shard, so the bound holds for every later queue as well
-  const size_t raygen_blocks = (samples + 255) / 256;
+  const size_t raygen_blocks = raygen_block_count(W, rows, u.samples_per_pixel);
   const size_t shard_cap = std::max<size_t>(256, ((raygen_blocks + N_SHARDS - 1) / N_SHARDS) * 256);
   const size_t capacity = shard_cap * N_SHARDS;
   int r = ensure_frame(c, capacity); if (r) return r;
