@@ -282,7 +282,9 @@ def main():
         _, cst = ctx.trace(WIDTH, HEIGHT, counting=True)
         mean_nodes = cst.node_visits / max(1, cst.closest_rays)
         mean_tris = cst.tri_tests / max(1, cst.closest_rays)
-        closest_rays_rank0 = st.closest_rays   # rays that entered the traversal kernel (survivors of the TLAS-root test + secondary)
+        # rays that entered the k_trace<closest> launches: survivors of the TLAS-root test, plus the secondary rays unless
+        # k_tail handled bounces >= 1 (its own launch, reported under frame_kernel_ms.tail)
+        closest_rays_rank0 = st.closest_rays - (st.rays_secondary if st.ms_tail > 0 else 0)
         alg_bytes = closest_rays_rank0 * (RAY_BYTES + HIT_BYTES + mean_nodes * cst.bvh_node_bytes + mean_tris * cst.bvh_tri_bytes)
         launches = max(1, st.launches_trace_closest)
         live_s = st.ms_trace_closest * 1e-3
@@ -290,7 +292,7 @@ def main():
         achieved_iso = alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
         result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                               "traffic": None,
-                              "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore",
+                              "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore; bounces >= 1 run inside k_tail when few paths survive",
                               "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
                               "algorithmic_bytes_per_launch": alg_bytes / launches,
                               "timing": "HIP events on the kernel's own stream, live in the timed region: mean over context 0's %d timed frames (every %d-th step); with %d frames "
@@ -300,7 +302,7 @@ def main():
                               "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,
                               "node_bytes": cst.bvh_node_bytes, "tri_bytes": cst.bvh_tri_bytes,
                               "frame_kernel_ms": {"raygen": st.ms_raygen, "trace_closest": st.ms_trace_closest, "shade": st.ms_shade,
-                                                  "trace_shadow": st.ms_trace_shadow, "resolve": st.ms_resolve, "frame": st.ms_frame},
+                                                  "trace_shadow": st.ms_trace_shadow, "resolve": st.ms_resolve, "tail": st.ms_tail, "frame": st.ms_frame},
                               "note": "scene (BVH+triangles ~25 MB) and cube map (96 MiB) fit the 256 MiB Infinity Cache: HBM traffic << algorithmic bytes"}
         traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
         if os.path.exists(traffic_file):

@@ -92,7 +92,7 @@ typedef struct rt_stats {
   uint64_t closest_rays;     /* rays through the closest-hit traversal kernel (primary+secondary) */
   float ms_frame;            /* HIP-event time of the whole frame pipeline on the trace stream */
   float ms_raygen;
-  float ms_trace_closest;    /* sum over bounces of the closest-hit traversal kernel */
+  float ms_trace_closest;    /* sum over its launches of the closest-hit traversal kernel k_trace (not k_tail) */
   float ms_trace_shadow;     /* any-hit traversal kernel */
   float ms_shade;
   float ms_resolve;
@@ -100,7 +100,7 @@ typedef struct rt_stats {
   uint32_t launches_total;
   uint32_t timed_frames;     /* the ms_* fields are means over this many frames (all frames enqueued with timing on
                                 since the previous rt_get_stats / rt_trace) */
-  uint32_t reserved;
+  float ms_tail;             /* k_tail: bounces 1..maxBounceCount in one launch (0 when the per-bounce launches ran) */
   uint32_t bvh_node_bytes;   /* S_node, S_tri of the roofline formula */
   uint32_t bvh_tri_bytes;
 } rt_stats;

@@ -22,7 +22,7 @@ class RtStats(C.Structure):
                 ("diag", C.c_uint64 * 6), ("closest_rays", C.c_uint64),
                 ("ms_frame", C.c_float), ("ms_raygen", C.c_float), ("ms_trace_closest", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_shade", C.c_float), ("ms_resolve", C.c_float),
-                ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32), ("timed_frames", C.c_uint32), ("reserved", C.c_uint32),
+                ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32), ("timed_frames", C.c_uint32), ("ms_tail", C.c_float),
                 ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32)]
 
     def as_dict(self):

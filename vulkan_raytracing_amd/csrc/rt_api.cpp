@@ -47,7 +47,7 @@ struct Mesh {
 };
 
 struct TimedSpan { int cat; hipEvent_t a, b; };
-enum { CAT_RAYGEN = 0, CAT_TRACE, CAT_SHADE, CAT_SHADOW, CAT_RESOLVE, CAT_FRAME, CAT_N };
+enum { CAT_RAYGEN = 0, CAT_TRACE, CAT_SHADE, CAT_SHADOW, CAT_RESOLVE, CAT_FRAME, CAT_TAIL, CAT_N };
 
 }  // namespace
 
@@ -378,7 +378,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
       if (b == 1 && use_tail) {
         // every later bounce in one launch (src/shader.rgen:84 loop), leaving as soon as a queue is empty
-        Span sp(c, CAT_TRACE, s); launch_tail(sc, f, u, 1, c->counting, c->cfg, s);
+        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, 1, c->counting, c->cfg, s);
         break;
       }
       { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
@@ -432,12 +432,13 @@ int collect_stats(rt_ctx* c) {
       case CAT_SHADOW: st.ms_trace_shadow += ms; break;
       case CAT_RESOLVE: st.ms_resolve += ms; break;
       case CAT_FRAME: st.ms_frame += ms; break;
+      case CAT_TAIL: st.ms_tail += ms; break;
     }
     if (sp.cat != CAT_FRAME) st.launches_total++;
   }
   if (c->timed_frames > 1) {   // mean per frame over every frame recorded since the last read
     const float k = 1.0f / (float)c->timed_frames;
-    st.ms_raygen *= k; st.ms_trace_closest *= k; st.ms_shade *= k; st.ms_trace_shadow *= k; st.ms_resolve *= k; st.ms_frame *= k;
+    st.ms_raygen *= k; st.ms_trace_closest *= k; st.ms_shade *= k; st.ms_trace_shadow *= k; st.ms_resolve *= k; st.ms_frame *= k; st.ms_tail *= k;
     st.launches_trace_closest /= c->timed_frames; st.launches_total /= c->timed_frames;
   }
   st.timed_frames = c->timed_frames;
