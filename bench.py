@@ -118,6 +118,7 @@ def main():
                          "swapchainImageCount = minImageCount + 1 frames in flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: "
                          "4, one per HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--param", action="append", default=[], help="rt_set_param NAME=VALUE on every context (experiments), repeatable")
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
     ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray; 2 = 4-ary records, one lane per ray")
     ap.add_argument("--blocks-per-cu", type=int, default=None)
@@ -179,6 +180,9 @@ def main():
         geom, inst, u, sky, arm_label = build_scene(c, res)
         if args.variant is not None:
             c.set_param("trace_variant", args.variant)
+        for kv in args.param:
+            k, v = kv.split("=")
+            c.set_param(k, int(v))
         if args.blocks_per_cu is not None:
             c.set_param("trace_blocks_per_cu", args.blocks_per_cu)
         ctxs.append(c)

@@ -247,11 +247,23 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
     const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
     F3 qs, qb; uint3 rot;
     quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
+    // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
     const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
     const uint4 Q0 = rp[0], Q1 = rp[1];
     float tn;
-    survive = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
-    survive = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) || survive;
+    const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
+    const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) && Q1.w != Q1.z;
+    const int c0 = (int)Q1.z, c1 = (int)Q1.w;
+    survive = (h0 && c0 < 0) || (h1 && c1 < 0);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int ch = k ? c1 : c0;
+      if ((k ? h1 : h0) && ch >= 0 && !survive) {
+        const uint4* np = reinterpret_cast<const uint4*>(sc.blas_nodes + ch);
+        const uint4 N0 = np[0], N1 = np[1];
+        survive = slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn);
+      }
+    }
     if (!survive) {
       const F3 c = sample_sky(sc, mk3(d.x, d.y, -d.z));
       f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
@@ -1199,7 +1211,7 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
   TailArgs t{};
   t.tr = make_args(sc, f.counters, first_bounce, f.shard_cap, f.ovf_stack);
   t.tr.hit_a = f.hit_a; t.tr.hit_inst = f.hit_inst; t.tr.hint = f.hint;
-  t.tr.rays_per_lane = (uint32_t)cfg.rays_per_lane; t.tr.min_blocks = 8u;
+  t.tr.rays_per_lane = 1u; t.tr.min_blocks = 8u;   // few rays: one per lane, the bounce costs one ray lifetime
   t.sh = ShadeArgs{sc, f, u, first_bounce};
   t.first_bounce = (uint32_t)first_bounce;
   t.barrier = f.counters + CNT_BARRIER; t.fault = f.counters + CNT_FAULT;
