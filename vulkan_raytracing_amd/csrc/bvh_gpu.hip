@@ -118,23 +118,74 @@ __global__ __launch_bounds__(256) void k_radix_tree(const uint32_t* keys, int n,
 }
 
 // bottom-up: each leaf climbs; the second arrival at a node merges the children's boxes and continues
-__global__ __launch_bounds__(256) void k_propagate(const Box* tri_boxes, const uint32_t* sorted_ids, int n, const int2* children, const int* parent_internal,
-                                                   const int* parent_leaf, Box* node_boxes, uint32_t* flags) {
+__device__ __forceinline__ Box box_union(const Box& a, const Box& b) {
+  Box m;
+  for (int k = 0; k < 3; k++) { m.lo[k] = fminf(a.lo[k], b.lo[k]); m.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
+  return m;
+}
+__device__ __forceinline__ float box_half_area(const Box& b) {
+  const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
+// Bottom-up box propagation: leaves climb, the second arrival at a node owns the finished subtree below it.
+// ROTATE: before a node's box is stored, the owner tries the four tree rotations that exchange one child with a
+// grandchild of the other side (Kensler 2008) and keeps the one that shrinks the surface area of the re-formed
+// child most — the SAH cost of a tree with one triangle per leaf is the sum of its internal nodes' areas, and a
+// rotation changes exactly one of them.  Nothing outside the owned subtree is touched, so the pass is race free.
+template <bool ROTATE>
+__global__ __launch_bounds__(256) void k_propagate(const Box* tri_boxes, const uint32_t* sorted_ids, int n, int2* children, int* parent_internal,
+                                                   int* parent_leaf, Box* node_boxes, uint32_t* flags) {
   const int leaf = blockIdx.x * blockDim.x + threadIdx.x;
   if (leaf >= n) return;
+  auto box_of = [&](int ref) -> Box { return ref >= 0 ? node_boxes[ref] : tri_boxes[sorted_ids[~ref]]; };
+  auto set_parent = [&](int ref, int p) { if (ref >= 0) parent_internal[ref] = p; else parent_leaf[~ref] = p; };
   int node = parent_leaf[leaf];
   while (node >= 0) {
     __threadfence();
     if (atomicAdd(&flags[node], 1u) == 0u) return;   // first arrival: the sibling subtree is not finished yet
     __threadfence();
-    const int2 ch = children[node];
+    int2 ch = children[node];
     // (the acquire fence above invalidated this CU's L1, so plain loads see the sibling subtree's boxes)
-    Box a, b;
-    if (ch.x >= 0) a = node_boxes[ch.x]; else a = tri_boxes[sorted_ids[~ch.x]];
-    if (ch.y >= 0) b = node_boxes[ch.y]; else b = tri_boxes[sorted_ids[~ch.y]];
-    Box m;
-    for (int k = 0; k < 3; k++) { m.lo[k] = fminf(a.lo[k], b.lo[k]); m.hi[k] = fmaxf(a.hi[k], b.hi[k]); }
-    node_boxes[node] = m;
+    Box a = box_of(ch.x), b = box_of(ch.y);
+    if (ROTATE) {
+      float best = -1e-7f * box_half_area(box_union(a, b));   // only real improvements
+      int pick = 0;
+      Box nb{};   // box of the re-formed child
+      int2 l = make_int2(0, 0), r = make_int2(0, 0);
+      if (ch.y >= 0) {
+        r = children[ch.y];
+        const float old = box_half_area(b);
+        const Box c1 = box_union(a, box_of(r.y)), c2 = box_union(a, box_of(r.x));   // left <-> right.x / right.y
+        const float d1 = box_half_area(c1) - old, d2 = box_half_area(c2) - old;
+        if (d1 < best) { best = d1; pick = 1; nb = c1; }
+        if (d2 < best) { best = d2; pick = 2; nb = c2; }
+      }
+      if (ch.x >= 0) {
+        l = children[ch.x];
+        const float old = box_half_area(a);
+        const Box c3 = box_union(b, box_of(l.y)), c4 = box_union(b, box_of(l.x));   // right <-> left.x / left.y
+        const float d3 = box_half_area(c3) - old, d4 = box_half_area(c4) - old;
+        if (d3 < best) { best = d3; pick = 3; nb = c3; }
+        if (d4 < best) { best = d4; pick = 4; nb = c4; }
+      }
+      if (pick == 1 || pick == 2) {
+        // the left child goes down into the right child, the right child's x (pick 1) or y (pick 2) comes up
+        const int up = pick == 1 ? r.x : r.y, stay = pick == 1 ? r.y : r.x;
+        children[ch.y] = make_int2(ch.x, stay); set_parent(ch.x, ch.y);
+        node_boxes[ch.y] = nb;
+        ch = make_int2(up, ch.y); set_parent(up, node);
+        children[node] = ch;
+      } else if (pick == 3 || pick == 4) {
+        const int up = pick == 3 ? l.x : l.y, stay = pick == 3 ? l.y : l.x;
+        children[ch.x] = make_int2(stay, ch.y); set_parent(ch.y, ch.x);
+        node_boxes[ch.x] = nb;
+        ch = make_int2(ch.x, up); set_parent(up, node);
+        children[node] = ch;
+      }
+      if (pick) { a = box_of(ch.x); b = box_of(ch.y); }
+    }
+    node_boxes[node] = box_union(a, b);
     node = parent_internal[node];
   }
 }
@@ -405,7 +456,15 @@ int build_blas_gpu(const float* d_verts6, const uint32_t* d_idx, uint32_t n, hip
   }
   GB_TRY(hipMemsetAsync(flags, 0, n * sizeof(uint32_t), s));
   hipLaunchKernelGGL(k_radix_tree, dim3(nb), dim3(256), 0, s, keys2, (int)n, children, ranges, parent_internal, parent_leaf);
-  hipLaunchKernelGGL(k_propagate, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, parent_internal, parent_leaf, node_boxes, flags);
+  // box propagation; with one triangle per leaf, RT_LBVH_ROTATE passes (default 2) also apply tree rotations
+  int rotate_passes = max_leaf == 1 ? 2 : 0;
+  if (const char* e = getenv("RT_LBVH_ROTATE")) { const int v = atoi(e); if (v >= 0 && v <= 16 && max_leaf == 1) rotate_passes = v; }
+  if (rotate_passes == 0)
+    hipLaunchKernelGGL(k_propagate<false>, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, parent_internal, parent_leaf, node_boxes, flags);
+  for (int pass = 0; pass < rotate_passes; pass++) {
+    if (pass) GB_TRY(hipMemsetAsync(flags, 0, n * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_propagate<true>, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, parent_internal, parent_leaf, node_boxes, flags);
+  }
   hipLaunchKernelGGL(k_quant_params, dim3(1), dim3(64), 0, s, node_boxes, qparams);
   hipLaunchKernelGGL(k_emit_nodes, dim3(nb), dim3(256), 0, s, tri_boxes, vals2, (int)n, children, ranges, node_boxes, qparams, out.nodes, max_leaf);
   hipLaunchKernelGGL(k_emit_tris, dim3(nb), dim3(256), 0, s, d_verts6, d_idx, vals2, n, out.tris);
