@@ -405,7 +405,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   // ---- per-lane ray state
   bool need = true;
   uint32_t q = 0, sid = 0;
-  float tmin = 0.f, tmax = 0.f;
+  float tmin_ray = 0.f, tmax = 0.f;   // tmin is a per-ray value only in the raw mode; the pipeline uses one constant
   F3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), co = wo, cd = wd, qs = mk3(1, 1, 1), qb = mk3(0, 0, 0);
   uint3 rot = make_uint3(0u, 0u, 0u);
   float4 shc = make_float4(0, 0, 0, 0);
@@ -439,8 +439,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           q = chunk_base + ci;
           const float4 ro = s_rays[wave][0][ci], rd = s_rays[wave][1][ci];
           if (MODE == MODE_SHADOW) shc = s_rays[wave][2][ci];
-          if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
-          else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
+          if (MODE == MODE_RAW) { tmin_ray = ro.w; tmax = rd.w; }
+          else { tmax = ro.w; sid = __float_as_uint(rd.w); }
           wo = mk3(ro.x, ro.y, ro.z); wd = mk3(rd.x, rd.y, rd.z);
           co = wo; cd = wd;
           quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
@@ -465,10 +465,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           const uint4 X = np[0], Y = np[1], Z = np[2], R = np[3];
           if (COUNT) cnt_nodes++;
           float t0, t1, t2, t3;
-          const bool h0 = slab_q(X.x, Y.x, Z.x, qs, qb, rot, tmin, best_t, t0);
-          const bool h1 = slab_q(X.y, Y.y, Z.y, qs, qb, rot, tmin, best_t, t1);
-          const bool h2 = slab_q(X.z, Y.z, Z.z, qs, qb, rot, tmin, best_t, t2);
-          const bool h3 = slab_q(X.w, Y.w, Z.w, qs, qb, rot, tmin, best_t, t3);
+          const bool h0 = slab_q(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+          const bool h1 = slab_q(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+          const bool h2 = slab_q(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2);
+          const bool h3 = slab_q(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3);
           // entry distance with the entry number in its two low mantissa bits; a miss sorts last
           uint32_t k0 = h0 ? (__float_as_uint(t0) & ~3u) : 0xFFFFFFFFu;
           uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFFu;
@@ -513,8 +513,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
-        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, tmin, best_t, t0);
-        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, tmin, best_t, t1);
+        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
 #ifdef RT_EXP_EXTRA_VALU   // sensitivity experiment: a dependent chain of extra fmas per visit
         {
           float acc = t0;
@@ -560,7 +560,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
         if (COUNT) cnt_tris++;
         float tt, uu, vv;
-        if (tri_test(T0, T1, T2, co, cd, tmin, tmax, tt, uu, vv)) {
+        if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), tmax, tt, uu, vv)) {
           const int prim = (int)__float_as_uint(T2.y);
           const bool better = (best_inst < 0) || (tt < best_t) ||
                               (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
@@ -571,18 +571,20 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       else pop();
     }
     if (cur == REF_MARK) {
-      // leave the instance: back to the world-space ray and the TLAS
-      co = wo; cd = wd;
-      quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+      // leave the instance: back to the TLAS.  The world-space ray space is needed again only if the next entry is
+      // an interior TLAS node (a TLAS leaf sets up its own space, and the bottom sentinel ends the ray)
       cur_inst = -1;
       pop();
+      if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
     }
     if (cur < 0 && cur > REF_MARK && cur_inst < 0) {
       // TLAS leaf: enter the instance (ray -> object space, t preserved)
       const int ii = ~cur;
       const InstanceDev* I = a.sc.inst + ii;
-      if ((I->mask & 0xFFu) == 0u) pop();
-      else {
+      if ((I->mask & 0xFFu) == 0u) {
+        pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
+        if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+      } else {
         float m[12];
         const float4* mp = reinterpret_cast<const float4*>(I->w2o);
         float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
