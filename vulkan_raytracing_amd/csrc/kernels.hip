@@ -339,7 +339,7 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 template <int MODE, bool ANY, bool COUNT, bool WIDE>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS][64];
-  __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];
+  __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
   // Grid sizing on the device: the launch always has the full persistent grid, but a queue that holds only a
@@ -364,7 +364,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   // ---- work distribution (wave-uniform): prefetched chunk in registers, current chunk in LDS
   uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
   uint32_t pf_base = 0, pf_count = 0;
-  float4 pf_o = make_float4(0, 0, 0, 0), pf_d = pf_o, pf_c = pf_o;
+  float4 pf_o = make_float4(0, 0, 0, 0), pf_d = pf_o;
   uint32_t chunk_base = 0, chunk_count = 0, chunk_pos = 0;
   auto prefetch = [&]() {
     pf_count = 0;
@@ -378,12 +378,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     }
     if (lane < pf_count) {
       pf_o = a.ray_o[pf_base + lane]; pf_d = a.ray_d[pf_base + lane];
-      if (MODE == MODE_SHADOW) pf_c = a.sh_c[pf_base + lane];
     }
   };
   auto promote = [&]() {
     s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
-    if (MODE == MODE_SHADOW) s_rays[wave][2][lane] = pf_c;
     chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
     prefetch();
   };
@@ -396,7 +394,16 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       const float4 r = s_out[wave][lane];
       const int2 k = s_outq[wave][lane];
       if (MODE == MODE_CLOSEST) { a.hit_a[k.x] = r; a.hit_inst[k.x] = k.y; }
-      else if (MODE == MODE_SHADOW) a.sample_color[k.x] = r;
+      else if (MODE == MODE_SHADOW) {
+        // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit.  The light term of the
+        // shadow-queue entry is fetched here, once per result burst, instead of riding along in registers.
+        float cr = 0.08f, cg = 0.24f, cb = 0.08f;
+        if (r.x != 0.0f) {
+          const float4 shc = a.sh_c[(uint32_t)k.y];
+          cr = __builtin_fmaf(shc.w, shc.x, cr); cg = __builtin_fmaf(shc.w, shc.y, cg); cb = __builtin_fmaf(shc.w, shc.z, cb);
+        }
+        a.sample_color[(uint32_t)k.x] = make_float4(cr, cg, cb, 1.0f);
+      }
       else { HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = (int)__float_as_uint(r.w); h.inst = k.y; a.raw_out[k.x] = h; }
     }
     out_count = 0;
@@ -408,7 +415,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   float tmin_ray = 0.f, tmax = 0.f;   // tmin is a per-ray value only in the raw mode; the pipeline uses one constant
   F3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), co = wo, cd = wd, qs = mk3(1, 1, 1), qb = mk3(0, 0, 0);
   uint3 rot = make_uint3(0u, 0u, 0u);
-  float4 shc = make_float4(0, 0, 0, 0);
   float best_t = 0.f, best_u = 0.f, best_v = 0.f;
   int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
   // BLAS nodes, then the TLAS nodes (WIDE: the 64-byte 4-ary records with the same numbering)
@@ -438,7 +444,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           const uint32_t ci = chunk_pos + rank;
           q = chunk_base + ci;
           const float4 ro = s_rays[wave][0][ci], rd = s_rays[wave][1][ci];
-          if (MODE == MODE_SHADOW) shc = s_rays[wave][2][ci];
           if (MODE == MODE_RAW) { tmin_ray = ro.w; tmax = rd.w; }
           else { tmax = ro.w; sid = __float_as_uint(rd.w); }
           wo = mk3(ro.x, ro.y, ro.z); wd = mk3(rd.x, rd.y, rd.z);
@@ -560,7 +565,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
         if (COUNT) cnt_tris++;
         float tt, uu, vv;
-        if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), tmax, tt, uu, vv)) {
+        if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), (ANY ? best_t : tmax), tt, uu, vv)) {
           const int prim = (int)__float_as_uint(T2.y);
           const bool better = (best_inst < 0) || (tt < best_t) ||
                               (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
@@ -606,11 +611,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       if (fin) {
         const uint32_t slot = out_count + prefix_rank(fin_mask);
         if (MODE == MODE_SHADOW) {
-          // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
-          float r = 0.08f, g = 0.24f, b = 0.08f;
-          if (best_inst < 0) { r = __builtin_fmaf(shc.w, shc.x, r); g = __builtin_fmaf(shc.w, shc.y, g); b = __builtin_fmaf(shc.w, shc.z, b); }
-          s_out[wave][slot] = make_float4(r, g, b, 1.0f);
-          s_outq[wave][slot] = make_int2((int)sid, 0);
+          s_out[wave][slot].x = best_inst < 0 ? 1.0f : 0.0f;   // lit?
+          s_outq[wave][slot] = make_int2((int)sid, (int)q);
         } else {
           s_out[wave][slot] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
           s_outq[wave][slot] = make_int2((int)q, best_inst);
