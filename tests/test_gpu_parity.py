@@ -176,6 +176,28 @@ def test_sharded_equals_full_frame_bit_exact(ctx):
             shards.append(buf.cpu().numpy())
         out = tiling.assemble(shards, H, W, tiling.BAND_ROWS)
         assert np.array_equal(out, full)
+    # band heights other than the tile height (general row mapping of k_raygen) and an odd shard count
+    for band, n in ((5, 3), (16, 2), (3, 5)):
+        rows_max = tiling.max_shard_rows(H, band, n)
+        shards = []
+        for s in range(n):
+            buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+            ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+            ctx.synchronize()
+            shards.append(buf.cpu().numpy())
+        assert np.array_equal(tiling.assemble(shards, H, W, band), full)
+
+
+@pytest.mark.parametrize("spp", [3, 5, 7])
+def test_sample_counts_that_do_not_fill_a_workgroup(ctx, spp):
+    """k_raygen packs up to 4 samples of a tile into one workgroup: sample counts that are not multiples of 4, at a
+    frame size that is not a multiple of the 8x8 tile, against the oracle."""
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 2, spp, sky=scenes.synthetic_skybox(64), ctx=ctx)
+    W, H = 75, 37
+    gpu, st = ctx.trace(W, H)
+    ref, rc = sp.orc.render(W, H)
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
 
 
 def test_full_size_properties_cfg3(ctx):
