@@ -151,7 +151,7 @@ __global__ __launch_bounds__(256) void k_propagate(const Box* tri_boxes, const u
     if (ROTATE) {
       float best = -1e-7f * box_half_area(box_union(a, b));   // only real improvements
       int pick = 0;
-      Box nb{};   // box of the re-formed child
+      Box nb{}, nb2{};   // boxes of the re-formed child(ren)
       int2 l = make_int2(0, 0), r = make_int2(0, 0);
       if (ch.y >= 0) {
         r = children[ch.y];
@@ -169,7 +169,23 @@ __global__ __launch_bounds__(256) void k_propagate(const Box* tri_boxes, const u
         if (d3 < best) { best = d3; pick = 3; nb = c3; }
         if (d4 < best) { best = d4; pick = 4; nb = c4; }
       }
-      if (pick == 1 || pick == 2) {
+      if (ch.x >= 0 && ch.y >= 0) {
+        // grandchild <-> grandchild: the pairings {LL,RL}+{LR,RR} and {LL,RR}+{RL,LR}; two boxes change at once
+        const Box bll = box_of(l.x), blr = box_of(l.y), brl = box_of(r.x), brr = box_of(r.y);
+        const float old = box_half_area(a) + box_half_area(b);
+        const Box p5 = box_union(bll, brl), q5 = box_union(blr, brr);
+        const Box p6 = box_union(bll, brr), q6 = box_union(brl, blr);
+        const float d5 = box_half_area(p5) + box_half_area(q5) - old, d6 = box_half_area(p6) + box_half_area(q6) - old;
+        if (d5 < best) { best = d5; pick = 5; nb = p5; nb2 = q5; }
+        if (d6 < best) { best = d6; pick = 6; nb = p6; nb2 = q6; }
+      }
+      if (pick == 5 || pick == 6) {
+        // left keeps LL and takes RL (5) or RR (6); right takes LR and keeps the other one
+        const int take = pick == 5 ? r.x : r.y, keep = pick == 5 ? r.y : r.x;
+        children[ch.x] = make_int2(l.x, take); set_parent(take, ch.x);
+        children[ch.y] = pick == 5 ? make_int2(l.y, keep) : make_int2(keep, l.y); set_parent(l.y, ch.y);
+        node_boxes[ch.x] = nb; node_boxes[ch.y] = nb2;
+      } else if (pick == 1 || pick == 2) {
         // the left child goes down into the right child, the right child's x (pick 1) or y (pick 2) comes up
         const int up = pick == 1 ? r.x : r.y, stay = pick == 1 ? r.y : r.x;
         children[ch.y] = make_int2(ch.x, stay); set_parent(ch.x, ch.y);
