@@ -88,7 +88,9 @@ def armadillo_path(resources_dir, cache_dir=None, frequency=132):
     mtl = os.path.join(resources_dir, "armadillo.mtl")
     if os.path.exists(mtl) and not os.path.exists(os.path.join(cache_dir, "armadillo.mtl")):
         import shutil
-        shutil.copyfile(mtl, os.path.join(cache_dir, "armadillo.mtl"))
+        tmp_mtl = os.path.join(cache_dir, "armadillo.mtl.tmp%d" % os.getpid())   # several ranks may start at once
+        shutil.copyfile(mtl, tmp_mtl)
+        os.replace(tmp_mtl, os.path.join(cache_dir, "armadillo.mtl"))
     if not os.path.exists(path):
         tmp = path + ".tmp%d" % os.getpid()
         if hlib().rth_write_armadillo_standin(os.fsencode(tmp), frequency) != 0:
