@@ -6,10 +6,9 @@ supplied) + skybox_texture_sea, 1920x1080, depth 4 (maxBounceCount 3) + shadow r
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU, --frames-in-flight (4) independent frames in flight per GPU (the reference's swapchain keeps
-minImageCount + 1 frames in flight, src/main.cpp:1203, 2967), each on its own HIP stream — one per hardware queue of
-the HIP default (GPU_MAX_HW_QUEUES=4; 8 queues with 8 frames measured 13 % faster on a 1/8 shard but 13 % slower
-with 4 frames, so the default stays).  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
+One process per GPU, --frames-in-flight independent frames in flight per GPU (the reference's swapchain keeps
+minImageCount + 1 frames in flight, src/main.cpp:1203, 2967), each on its own HIP stream with its own hardware queue:
+4 frames / the 4 default queues on one GPU, 8 frames / GPU_MAX_HW_QUEUES=8 when the frame is sharded.  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
 x 4 bounces -> any-hit shadow traversal -> resolve, on this rank's interleaved 8-row bands, followed
 (N > 1) by ONE RCCL gather of the compact shards to rank 0 and the row permutation that reassembles
 the frame.  The frame is fixed, so scaling is STRONG.  Inputs (scene, BVH, cube map) are resident in
@@ -24,6 +23,12 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# A 1/N frame shard is latency-bound, so a sharded run keeps 8 frames in flight and gives each of their streams its own
+# hardware queue (HIP maps streams onto 4 by default; read at HIP start-up).  Measured on one GPU, rank 0's shard of an
+# 8-way split: 0.143 ms per frame with 4 frames / 4 queues, 0.124 ms with 8 / 8; a whole frame is 3 % slower with 8 / 8,
+# so a single-GPU run keeps the defaults.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -116,7 +121,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frames in flight per GPU, each on its own stream and buffers; the reference keeps "
                          "swapchainImageCount = minImageCount + 1 frames in flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: "
-                         "4, one per HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
+                         "4 on one GPU, 8 when the frame is split over several — one per HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--param", action="append", default=[], help="rt_set_param NAME=VALUE on every context (experiments), repeatable")
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
@@ -165,7 +170,7 @@ def main():
     n = world
     collective = n > 1 or args.force_collective
     assert args.gpus == n, "--gpus must equal the number of launched ranks"
-    P = args.frames_in_flight if args.frames_in_flight > 0 else 4
+    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n == 1 else 8)
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:

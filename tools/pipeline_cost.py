@@ -24,7 +24,7 @@ def main():
         ctxs.append(c)
     print("params", params, flush=True)
     streams = [torch.cuda.Stream() for _ in ctxs]
-    for n in (1, 8):
+    for n in [int(x) for x in os.environ.get("N_LIST", "1,8").split(",")]:
         rows = tiling.max_shard_rows(H, band, n)
         bufs = [torch.zeros((rows, W, 4), dtype=torch.float32, device="cuda:0") for _ in ctxs]
         for P in [int(x) for x in os.environ.get("P_LIST", "1,2,3,4,6,8").split(",")]:
