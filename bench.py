@@ -199,7 +199,8 @@ def main():
     # the gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183),
     # so 25 % of the xGMI traffic into rank 0 would be constants
     gathered = [torch.zeros((n, rows_max, WIDTH, 3), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
-    full = [torch.ones((HEIGHT, WIDTH, 4), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
+    # the assembled frame on rank 0 stays RGB (alpha is the constant 1.0): the row permutation writes it in one kernel
+    full = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
     perm = None
     if rank == 0 and collective:
         src = np.zeros(HEIGHT, np.int64)
@@ -227,7 +228,7 @@ def main():
                 rgb = shards[j][..., :3].contiguous()
                 dist.gather(rgb, list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
                 if rank == 0:
-                    full[j][..., :3] = gathered[j].view(n * rows_max, WIDTH, 3).index_select(0, perm)
+                    torch.index_select(gathered[j].view(n * rows_max, WIDTH, 3), 0, perm, out=full[j])
                     frames[j] = full[j]
             else:
                 frames[j] = shards[j]
@@ -322,6 +323,8 @@ def main():
         last = (counter[0] - 1) % P
         if args.save_image and frames[last] is not None:
             img = frames[last][:HEIGHT].cpu().numpy()
+            if img.shape[-1] == 3:   # assembled multi-rank frame: RGB + the constant alpha
+                img = np.concatenate([img, np.ones(img.shape[:2] + (1,), np.float32)], axis=-1)
             with open(args.save_image, "wb") as fh:
                 fh.write(b"PF4\n%d %d\n-1.0\n" % (WIDTH, HEIGHT))
                 fh.write(img[::-1].astype("<f4").tobytes())
