@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -48,7 +49,8 @@ static void writePPM(const std::string& path, const std::vector<float>& rgba, in
 
 int main(int argc, char** argv) {
   int W = 800, H = 600;  // the reference's window size (src/main.cpp:805)
-  int frames = 3, device = 0;
+  int frames = 3, device = 0, inFlight = 1;
+  bool rgba8 = false;
   float dt = 1.0f / 60.0f;
   std::string center = CENTER_MESH_OBJ_PATH, orbiting = ORBITING_MESH_OBJ_PATH, skyDir = SKYBOX_TEXTURE_DIR, out = "frame";
   rt_uniforms uniformStructure = rthost::defaultUniforms();
@@ -68,6 +70,8 @@ int main(int argc, char** argv) {
     else if (a == "--skybox") skyDir = next();
     else if (a == "--out") out = next();
     else if (a == "--device") device = atoi(next());
+    else if (a == "--rgba8") rgba8 = true;   // frames come back in the 8-bit surface format the reference presents (src/main.cpp:1899); needs --frames-in-flight > 1
+    else if (a == "--frames-in-flight") inFlight = std::max(1, atoi(next()));   // the reference: swapchain image count, src/main.cpp:1203
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
   try {
@@ -115,6 +119,72 @@ int main(int argc, char** argv) {
     Camera camera;  // (0,0,20) looking down -z (src/camera.cpp:8-14)
     std::vector<float> image;
     float timeParam = 0.f;
+    if (inFlight > 1) {
+      // Frames in flight, as the reference's swapchain loop has them (src/main.cpp:2905-2967): one Renderer (context,
+      // scene replica, pinned output) per frame in flight; a frame is submitted, and collected when its Renderer comes
+      // round again.  The pixels of every frame land in host memory, so the rate below includes the PCIe copy.
+      std::vector<std::unique_ptr<rthost::Renderer>> ring;
+      ring.push_back(nullptr);
+      for (int k = 1; k < inFlight; k++) {
+        ring.emplace_back(new rthost::Renderer(device));
+        ring[k]->uploadGeometry(geometry);
+        ring[k]->setInstances(makeInstances(), false);
+        ring[k]->setSkybox(sky, sw, sh);
+        ring[k]->setUniforms(uniformStructure);
+      }
+      auto at = [&](int k) -> rthost::Renderer& { return k == 0 ? renderer : *ring[k]; };
+      for (int k = 0; k < inFlight; k++) { at(k).setParam("trace_blocks_per_cu", 4); at(k).setParam("output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); }
+      std::vector<char> pending(inFlight, 0);
+      uint64_t rays = 0; int collected = 0;
+      const void* px = nullptr;
+      double submitMs = 0.0, waitMs = 0.0;
+      auto collect = [&](int k) {
+        auto w0 = std::chrono::steady_clock::now();
+        rt_stats st = at(k).wait(px);
+        waitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - w0).count();
+        rays += st.rays_primary + st.rays_secondary + st.rays_shadow; collected++; pending[k] = 0;
+      };
+      const int warm = std::min(frames, inFlight);   // the first frame of every context allocates its queues
+      std::chrono::steady_clock::time_point t0;
+      for (int frame = 0; frame < frames + warm; frame++) {
+        const int k = frame % inFlight;
+        if (pending[k]) collect(k);
+        if (frame == warm) {   // drain, then start the clock
+          for (int j = 0; j < inFlight; j++) if (pending[j]) collect(j);
+          rays = 0; collected = 0; submitMs = waitMs = 0.0; t0 = std::chrono::steady_clock::now();
+        }
+        timeParam += dt * 0.1f;
+        animation.animate(timeParam);
+        at(k).setInstances(makeInstances(), true);   // createTLAS(update = true), src/main.cpp:2853-2861
+        at(k).setUniforms(uniformStructure);         // copyData(uniform), src/main.cpp:2901-2903
+        { auto s0 = std::chrono::steady_clock::now(); at(k).submit(W, H); submitMs += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - s0).count(); }
+        pending[k] = 1;
+      }
+      int last = (frames + warm - 1) % inFlight;
+      for (int j = 1; j <= inFlight; j++) { const int k = (last + j) % inFlight; if (pending[k]) collect(k); }   // oldest first; the newest frame is collected last
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      printf("%d frames, %d in flight: %dx%d  %.3f ms per frame  %.1f Mrays/s with every frame copied to host memory as %s  mesh: %s\n", collected, inFlight, W, H,
+             ms / collected, rays / (ms * 1e3), rgba8 ? "RGBA8" : "RGBA32F", meshLabel.c_str());
+      printf("host time per frame: submit %.3f ms, wait %.3f ms\n", submitMs / collected, waitMs / collected);
+      if (rgba8) {
+        const unsigned char* b = static_cast<const unsigned char*>(px);
+        std::ofstream f(out + ".ppm", std::ios::binary);
+        f << "P6\n" << W << " " << H << "\n255\n";
+        std::vector<unsigned char> row((size_t)W * 3);
+        for (int y = 0; y < H; y++) {
+          for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = b[((size_t)y * W + x) * 4 + c];
+          f.write((const char*)row.data(), (std::streamsize)row.size());
+        }
+        printf("wrote %s.ppm (8-bit frame as stored by the device)\n", out.c_str());
+        return 0;
+      }
+      const float* pf = static_cast<const float*>(px);
+      image.assign(pf, pf + (size_t)W * H * 4);
+      writePFM(out + ".pfm", image, W, H);
+      writePPM(out + ".ppm", image, W, H);
+      printf("wrote %s.pfm (float32) and %s.ppm (8-bit clamped view)\n", out.c_str(), out.c_str());
+      return 0;
+    }
     for (int frame = 0; frame < frames; frame++) {
       // main loop body (src/main.cpp:2795-2949) with a fixed time step instead of the wall clock
       timeParam += dt * 0.1f;

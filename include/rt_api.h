@@ -142,6 +142,14 @@ int rt_trace(rt_ctx* ctx, int width, int height, float* out_rgba32f_host, rt_sta
  * Returns immediately; use rt_synchronize / the stream to wait.  out_capacity_bytes guards d_out. */
 int rt_trace_shard(rt_ctx* ctx, int width, int height, int band_rows, int shard, int n_shards,
                    void* d_out, size_t out_capacity_bytes, void* hip_stream);
+/* Frames in flight from a plain C/C++ host: rt_trace_async enqueues the frame and its copy to a pinned host buffer owned
+ * by the context and returns (vkQueueSubmit with a fence, src/main.cpp:2905-2967); rt_trace_wait blocks until that frame
+ * is complete (vkWaitForFences, src/main.cpp:772-778) and hands out the pixels (W*H*4 floats, or W*H*4 bytes with
+ * rt_set_param "output_rgba8" 1; valid until the next rt_trace_async on this context) and the frame's counters.  One frame per context may be pending; a host that wants P
+ * frames in flight keeps P contexts, as the reference keeps one command buffer, fence and image per swapchain image. */
+int rt_trace_async(rt_ctx* ctx, int width, int height);
+int rt_trace_wait(rt_ctx* ctx, const void** pixels, rt_stats* stats);
+
 /* number of rows rt_trace_shard writes for (height, band_rows, shard, n_shards) */
 int rt_shard_rows(int height, int band_rows, int shard, int n_shards);
 
@@ -154,6 +162,8 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
 /* Tunables (no reference counterpart): "trace_variant" 0 = quantized BVH2 / one lane per ray (default), 1 = BVH4 /
  * four lanes per ray, 2 = 4-ary records / one lane per ray; "tail_kernel" 0 = one launch per bounce and kernel, 1 = bounces
  * 1..maxBounceCount in one launch when the previous frame had few secondary rays (default), 2 = always;
+ * "output_rgba8" 1 = every entry point that returns a frame stores 8-bit RGBA (clamp to [0,1], x255, round; the format
+ * the reference's storage image really has, src/main.cpp:1899) instead of RGBA32F — a quarter of the PCIe bytes;
  * "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device LBVH (default:
  * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357), 0 = host binned-SAH;
  * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids.  Results do not depend on any of them. */

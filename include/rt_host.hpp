@@ -185,6 +185,11 @@ class Renderer {
     check(rt_trace(ctx_, W, H, rgba.data(), &st), "rt_trace");
     return st;
   }
+  // frames in flight (one pending frame per Renderer): submit = vkQueueSubmit + fence, wait = vkWaitForFences
+  void submit(int W, int H) { check(rt_trace_async(ctx_, W, H), "rt_trace_async"); }
+  // pixels: W*H*4 floats, or W*H*4 bytes after setParam("output_rgba8", 1)
+  rt_stats wait(const void*& pixels) { rt_stats st{}; check(rt_trace_wait(ctx_, &pixels, &st), "rt_trace_wait"); return st; }
+  void setParam(const char* name, int value) { check(rt_set_param(ctx_, name, value), "rt_set_param"); }
   void setTiming(bool on) { check(rt_set_timing(ctx_, on ? 1 : 0), "rt_set_timing"); }
 
  private:

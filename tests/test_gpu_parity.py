@@ -12,6 +12,7 @@ import pytest
 
 from tests import scenes
 from vulkan_raytracing_amd import RtContext, host, tiling
+from vulkan_raytracing_amd.api import RtError
 
 pytestmark = pytest.mark.gpu
 RES = scenes.RES
@@ -232,6 +233,45 @@ def test_error_behaviour(ctx):
     with pytest.raises(RtError):
         RtContext(99)
     c.close()
+
+
+def test_frames_in_flight_async_entry_points(ctx):
+    """rt_trace_async / rt_trace_wait (submit + fence of src/main.cpp:2905-2967): same pixels and counters as the
+    blocking rt_trace, several contexts pending at once, and the call-order errors."""
+    paths = (os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"))
+    W, H = 200, 120
+    sp = scenes.two_object_scene(paths[0], paths[1], 2, 1, 4, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.3)
+    ref, st_ref = ctx.trace(W, H)
+    with pytest.raises(RtError):
+        ctx.trace_wait()                      # nothing submitted
+    others = [RtContext(0) for _ in range(2)]
+    try:
+        for c in others:
+            scenes.two_object_scene(paths[0], paths[1], 2, 1, 4, 2, sky=scenes.synthetic_skybox(64), ctx=c, time_param=0.3)
+        ring = [ctx] + others
+        for _ in range(3):                    # three rounds, three frames pending each time
+            for c in ring:
+                c.trace_async(W, H)
+            with pytest.raises(RtError):
+                ring[0].trace_async(W, H)     # one pending frame per context
+            for c in ring:
+                img, st = c.trace_wait()
+                assert np.array_equal(img, ref)
+                assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (st_ref.rays_primary, st_ref.rays_secondary, st_ref.rays_shadow)
+        # 8-bit surface-format output (src/main.cpp:1899): clamp, x255, round — through both the blocking and the async entry
+        try:
+            ctx.set_param("output_rgba8", 1)
+            want = (np.clip(ref, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+            img8, _ = ctx.trace(W, H)
+            assert img8.dtype == np.uint8 and np.array_equal(img8, want)
+            ctx.trace_async(W, H)
+            img8b, _ = ctx.trace_wait()
+            assert np.array_equal(img8b, want)
+        finally:
+            ctx.set_param("output_rgba8", 0)
+    finally:
+        for c in others:
+            c.close()
 
 
 def test_trace_variants_are_result_identical(ctx):

@@ -34,7 +34,7 @@ class RtStats(C.Structure):
 
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
-           "rt_trace", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
+           "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
            "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
 _LIB = None
@@ -55,6 +55,8 @@ def lib():
         L.rt_set_skybox.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int]
         L.rt_trace.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(RtStats)]
         L.rt_trace_counting.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(RtStats)]
+        L.rt_trace_async.argtypes = [vp, C.c_int, C.c_int]
+        L.rt_trace_wait.argtypes = [vp, C.POINTER(vp), C.POINTER(RtStats)]
         L.rt_trace_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.rt_shard_rows.argtypes = [C.c_int] * 4
         L.rt_synchronize.argtypes = [vp]
@@ -144,7 +146,7 @@ class RtContext:
         self._chk(self.L.rt_set_skybox(self.h, arr, w, h), "rt_set_skybox")
 
     def trace(self, W, H, counting=False):
-        out = np.zeros((H, W, 4), np.float32)
+        out = np.zeros((H, W, 4), np.uint8 if getattr(self, "_rgba8", False) else np.float32)
         st = RtStats()
         fn = self.L.rt_trace_counting if counting else self.L.rt_trace
         self._chk(fn(self.h, W, H, _p(out), C.byref(st)), "rt_trace")
@@ -152,6 +154,22 @@ class RtContext:
 
     def shard_rows(self, H, band_rows, shard, n_shards):
         return self.L.rt_shard_rows(H, band_rows, shard, n_shards)
+
+    def trace_async(self, W, H):
+        """Enqueue a frame and its copy to the context's pinned host buffer; returns at once (one pending frame per context)."""
+        self._chk(self.L.rt_trace_async(self.h, W, H), "rt_trace_async")
+        self._async_shape = (H, W, 4)
+
+    def trace_wait(self, copy=True):
+        """Wait for the frame of trace_async; returns (pixels, stats).  With copy=False the array aliases the pinned
+        buffer and is valid until the next trace_async on this context."""
+        px = C.c_void_p()
+        st = RtStats()
+        self._chk(self.L.rt_trace_wait(self.h, C.byref(px), C.byref(st)), "rt_trace_wait")
+        H, W, _ = self._async_shape
+        ct = C.c_uint8 if getattr(self, "_rgba8", False) else C.c_float
+        img = np.ctypeslib.as_array(C.cast(px, C.POINTER(ct)), shape=(H, W, 4))
+        return (img.copy() if copy else img), st
 
     def trace_shard(self, W, H, band_rows, shard, n_shards, d_out_ptr, capacity_bytes, stream_ptr=None):
         self._chk(self.L.rt_trace_shard(self.h, W, H, band_rows, shard, n_shards, C.c_void_p(d_out_ptr), capacity_bytes,
@@ -170,6 +188,8 @@ class RtContext:
 
     def set_param(self, name, value):
         self._chk(self.L.rt_set_param(self.h, name.encode(), int(value)), "rt_set_param")
+        if name == "output_rgba8":
+            self._rgba8 = bool(value)   # frames come back as uint8 (H, W, 4)
 
     def intersect(self, rays8, any_hit=False, counting=False):
         rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)

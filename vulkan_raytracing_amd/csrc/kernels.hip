@@ -1129,14 +1129,45 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
 __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
   const uint32_t npx = (uint32_t)(f.rows * f.width);
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= npx) return;
-  float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
-  for (uint32_t i = 0; i < u.samples_per_pixel; i++) {
-    const float4 c = f.sample_color[(size_t)i * npx + p];
-    r += c.x; g += c.y; b += c.z; al += c.w;
+  if (p < npx) {
+    float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
+    for (uint32_t i = 0; i < u.samples_per_pixel; i++) {
+      const float4 c = f.sample_color[(size_t)i * npx + p];
+      r += c.x; g += c.y; b += c.z; al += c.w;
+    }
+    const float nn = (float)u.samples_per_pixel;
+    const float4 px = make_float4(r / nn, g / nn, b / nn, al / nn);
+    if (f.out_rgba8) {
+      // the reference's storage image really has the 8-bit surface format (src/main.cpp:1899): clamp to [0,1], scale, round
+      auto q = [](float v) -> unsigned char { v = fminf(fmaxf(v, 0.0f), 1.0f); return (unsigned char)(v * 255.0f + 0.5f); };
+      reinterpret_cast<uchar4*>(f.out)[p] = make_uchar4(q(px.x), q(px.y), q(px.z), q(px.w));
+    } else {
+      f.out[p] = px;
+    }
   }
-  const float nn = (float)u.samples_per_pixel;
-  f.out[p] = make_float4(r / nn, g / nn, b / nn, al / nn);
+  // This is the last kernel of the frame, so every counter is final: workgroup 0 condenses them into the host-mapped
+  // statistics block (rt_device.h StatSlot).
+  if (blockIdx.x == 0 && f.stats_out) {
+    __shared__ unsigned long long s_q[N_QUEUES];
+    const uint32_t t = threadIdx.x;
+    if (t < (uint32_t)N_QUEUES) {
+      unsigned long long n = 0;
+      for (int k = 0; k < N_SHARDS; k++) n += ld_cursor(f.counters + cnt_tail((int)t, k));
+      s_q[t] = n;
+    }
+    __syncthreads();
+    auto put = [&](int slot, unsigned long long v) { __hip_atomic_store(f.stats_out + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    auto cnt64 = [&](int word) { return (unsigned long long)ld_cursor(f.counters + word) | ((unsigned long long)ld_cursor(f.counters + word + 1) << 32); };
+    if (t == 0) {
+      unsigned long long sec = 0;
+      for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) sec += s_q[b];
+      put(STAT_QUEUE0, s_q[0]); put(STAT_SECONDARY, sec); put(STAT_SHADOW, s_q[Q_SHADOW]); put(STAT_QUEUE1, s_q[1]);
+      put(STAT_FAULT, ld_cursor(f.counters + CNT_FAULT));
+      put(STAT_NODE_VISITS, cnt64(CNT_NODE_VISITS)); put(STAT_TRI_TESTS, cnt64(CNT_TRI_TESTS));
+      put(STAT_NODE_VISITS_SH, cnt64(CNT_NODE_VISITS_SH)); put(STAT_TRI_TESTS_SH, cnt64(CNT_TRI_TESTS_SH));
+      for (int k = 0; k < 3; k++) { put(STAT_DIAG + k, cnt64(CNT_DIAG + 2 * k)); put(STAT_DIAG + 3 + k, cnt64(CNT_DIAG_SH + 2 * k)); }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

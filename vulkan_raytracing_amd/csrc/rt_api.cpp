@@ -98,10 +98,18 @@ struct rt_ctx {
   size_t frame_capacity = 0;     // rays
   size_t out_capacity = 0;       // float4 pixels in lib-owned output
   float4* d_out_own = nullptr;
+  float4* h_out_pinned = nullptr;   // rt_trace_async: pinned host copy of the frame
+  size_t pinned_capacity = 0;      // float4 pixels
+  bool out_rgba8 = false;          // "output_rgba8": frames are stored as 8-bit RGBA (4 bytes per pixel) instead of RGBA32F
+  bool async_pending = false;
+  int async_w = 0, async_h = 0;
   uint32_t* d_counters = nullptr;
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
+  unsigned long long* h_stats = nullptr;   // pinned, device-visible StatSlot block written by k_resolve
+  unsigned long long* d_stats = nullptr;
+  bool last_empty = false;       // the last enqueued frame had no rows (nothing was launched)
   uint32_t* h_hint = nullptr;    // pinned, device-visible word: size of bounce queue 1 in the most recent frame that reached
   uint32_t* d_hint = nullptr;    // bounce 1 (written by the kernels; a speed hint only, never affects results)
   int blas_builder = 1;          // 1: device LBVH (bvh_gpu.hip, default), 0: host binned-SAH
@@ -303,6 +311,11 @@ int ensure_common(rt_ctx* c) {
     *c->h_hint = 0xFFFFFFFFu;   // unknown: the first frame takes one launch per bounce
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_hint, c->h_hint, 0));
   }
+  if (!c->h_stats) {
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_stats, STAT_WORDS * sizeof(unsigned long long), hipHostMallocMapped));
+    memset(c->h_stats, 0, STAT_WORDS * sizeof(unsigned long long));
+    HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_stats, c->h_stats, 0));
+  }
   if (c->d_ovf && c->ovf_alloc_stride < c->ovf_stride) { HIP_TRY(c, hipFree(c->d_ovf)); c->d_ovf = nullptr; }
   if (!c->d_ovf) {
     HIP_TRY(c, hipMalloc((void**)&c->d_ovf, (size_t)c->cfg.trace_blocks * 256 * c->ovf_stride * sizeof(int32_t)));
@@ -357,7 +370,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   const size_t capacity = shard_cap * N_SHARDS;
   int r = ensure_frame(c, capacity); if (r) return r;
   FrameDev f = c->frame;
-  f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out; f.hint = c->d_hint;
+  f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out; f.out_rgba8 = c->out_rgba8 ? 1 : 0; f.hint = c->d_hint; f.stats_out = c->d_stats;
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   const SceneDev sc = scene_dev(c);
@@ -368,6 +381,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   c->frame_stream = s; c->frame_pending = true;
   c->last_max_bounce = u.max_bounce_count;
   c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
+  c->last_empty = rows == 0;
   if (rows == 0) { HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s)); return RT_OK; }
   {
     Span frame_span(c, CAT_FRAME, s);
@@ -402,25 +416,24 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
 
 int collect_stats(rt_ctx* c) {
   if (!c->frame_pending) return RT_OK;
+  // k_resolve has written the frame's statistics block to host-mapped memory: nothing to copy.  (A device-to-host
+  // copy of the counters here, behind the pixel copy of rt_trace_async, serialised the frames of other contexts.)
   HIP_TRY(c, hipStreamSynchronize(c->frame_stream));
-  std::vector<uint32_t> cnt(CNT_WORDS);
-  HIP_TRY(c, hipMemcpy(cnt.data(), c->d_counters, CNT_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost));
-  auto queue_size = [&](int qi) { uint64_t n = 0; for (int t = 0; t < N_SHARDS; t++) n += cnt[cnt_tail(qi, t)]; return n; };
+  const unsigned long long* hs = c->h_stats;
   rt_stats st{};
   st.rays_primary = c->last_primary;
-  for (uint32_t b = 1; b <= c->last_max_bounce; b++) st.rays_secondary += queue_size((int)b);
-  st.rays_shadow = queue_size(Q_SHADOW);
-  *c->h_hint = (uint32_t)std::min<uint64_t>(queue_size(1), 0xFFFFFFFFu);
-  if (cnt[CNT_FAULT] != 0) { c->frame_pending = false; return fail(c, RT_ERR_DEVICE, "k_tail: a grid barrier did not complete (frame discarded)"); }
-  // rays that went through the closest-hit traversal kernel: primary rays that survived the TLAS-root
-  // test fused into k_raygen (queue 0) plus every secondary ray
-  st.closest_rays = queue_size(0) + st.rays_secondary;
-  memcpy(&st.node_visits, &cnt[CNT_NODE_VISITS], 8);
-  memcpy(&st.tri_tests, &cnt[CNT_TRI_TESTS], 8);
-  memcpy(&st.node_visits_shadow, &cnt[CNT_NODE_VISITS_SH], 8);
-  memcpy(&st.tri_tests_shadow, &cnt[CNT_TRI_TESTS_SH], 8);
-  memcpy(&st.diag[0], &cnt[CNT_DIAG], 24);
-  memcpy(&st.diag[3], &cnt[CNT_DIAG_SH], 24);
+  if (!c->last_empty) {
+    st.rays_secondary = hs[STAT_SECONDARY];
+    st.rays_shadow = hs[STAT_SHADOW];
+    *c->h_hint = (uint32_t)std::min<uint64_t>(hs[STAT_QUEUE1], 0xFFFFFFFFu);
+    if (hs[STAT_FAULT] != 0) { c->frame_pending = false; return fail(c, RT_ERR_DEVICE, "k_tail: a grid barrier did not complete (frame discarded)"); }
+    // rays that went through the closest-hit traversal kernel: primary rays that survived the TLAS
+    // test fused into k_raygen (queue 0) plus every secondary ray
+    st.closest_rays = hs[STAT_QUEUE0] + st.rays_secondary;
+    st.node_visits = hs[STAT_NODE_VISITS]; st.tri_tests = hs[STAT_TRI_TESTS];
+    st.node_visits_shadow = hs[STAT_NODE_VISITS_SH]; st.tri_tests_shadow = hs[STAT_TRI_TESTS_SH];
+    for (int k = 0; k < 6; k++) st.diag[k] = hs[STAT_DIAG + k];
+  }
   st.bvh_node_bytes = c->cfg.variant == 1 ? sizeof(Bvh4Node) : c->cfg.variant == 2 ? sizeof(WideNodeQ) : sizeof(BvhNodeQ); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
     float ms = 0.f;
@@ -453,7 +466,7 @@ int collect_stats(rt_ctx* c) {
 // ================================================================================================
 extern "C" {
 
-int rt_abi_version(void) { return 1; }
+int rt_abi_version(void) { return 2; }   // 2: rt_trace_async / rt_trace_wait, rt_stats::ms_tail
 
 int rt_create(rt_ctx** out_ctx, int device_id) {
   if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
@@ -496,6 +509,8 @@ void rt_destroy(rt_ctx* c) {
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
+  if (c->h_out_pinned) hipHostFree(c->h_out_pinned);
+  if (c->h_stats) hipHostFree(c->h_stats);
   for (auto e : c->ev_pool) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -680,6 +695,11 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     if (c->d_ovf && value * c->n_cu > c->cfg.trace_blocks) { hipFree(c->d_ovf); c->d_ovf = nullptr; }
     c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
   }
+  if (k == "output_rgba8") {
+    if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "output_rgba8 must be 0 or 1");
+    if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "output_rgba8 cannot change while a frame is pending");
+    c->out_rgba8 = value != 0; return RT_OK;
+  }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); c->blas_builder = value; return RT_OK; }
   if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
@@ -773,7 +793,7 @@ int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shar
   HIP_TRY(c, hipSetDevice(c->device));
   int r = ready_to_trace(c); if (r) return r;
   const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
-  if ((size_t)rows * W * 16 > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for this shard");
+  if ((size_t)rows * W * (c->out_rgba8 ? 4 : 16) > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for this shard");
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
   return enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
 }
@@ -809,12 +829,53 @@ static int trace_host(rt_ctx* c, int W, int H, float* out, rt_stats* stats, bool
   c->counting = false;
   if (r) return r;
   r = collect_stats(c); if (r) return r;
-  HIP_TRY(c, hipMemcpy(out, c->d_out_own, px * sizeof(float4), hipMemcpyDeviceToHost));
+  HIP_TRY(c, hipMemcpy(out, c->d_out_own, px * (c->out_rgba8 ? 4 : sizeof(float4)), hipMemcpyDeviceToHost));
   if (stats) *stats = c->last;
   return RT_OK;
 }
 
 int rt_trace(rt_ctx* c, int W, int H, float* out, rt_stats* stats) { return trace_host(c, W, H, out, stats, false); }
+
+// vkQueueSubmit + fence of the reference's frame loop (src/main.cpp:2905-2967): the frame and its copy to a pinned host
+// buffer are enqueued on the context's stream and the call returns; a host keeps several contexts in flight.
+int rt_trace_async(rt_ctx* c, int W, int H) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (W <= 0 || H <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace_async arguments");
+  if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "rt_trace_async: the previous frame of this context has not been collected (rt_trace_wait)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t px = (size_t)W * H;
+  if (px > c->out_capacity) {
+    if (c->d_out_own) HIP_TRY(c, hipFree(c->d_out_own));
+    c->d_out_own = nullptr; c->out_capacity = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_out_own, px * sizeof(float4)));
+    c->out_capacity = px;
+  }
+  if (px > c->pinned_capacity) {
+    if (c->h_out_pinned) HIP_TRY(c, hipHostFree(c->h_out_pinned));
+    c->h_out_pinned = nullptr; c->pinned_capacity = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_out_pinned, px * sizeof(float4), hipHostMallocDefault));
+    c->pinned_capacity = px;
+  }
+  int r = rt_trace_shard(c, W, H, H, 0, 1, c->d_out_own, px * sizeof(float4), nullptr);
+  if (r) return r;
+  HIP_TRY(c, hipMemcpyAsync(c->h_out_pinned, c->d_out_own, px * (c->out_rgba8 ? 4 : sizeof(float4)), hipMemcpyDeviceToHost, c->stream));
+  c->async_pending = true; c->async_w = W; c->async_h = H;
+  return RT_OK;
+}
+
+// vkWaitForFences (src/main.cpp:772-778) for the frame submitted with rt_trace_async; *pixels stays valid until the
+// next rt_trace_async on this context.
+int rt_trace_wait(rt_ctx* c, const void** pixels, rt_stats* stats) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (!c->async_pending) return fail(c, RT_ERR_NOT_READY, "rt_trace_wait without rt_trace_async");
+  HIP_TRY(c, hipSetDevice(c->device));
+  c->async_pending = false;
+  int r = collect_stats(c); if (r) return r;          // waits for the frame's kernels
+  HIP_TRY(c, hipStreamSynchronize(c->stream));        // ... and for the copy behind them
+  if (pixels) *pixels = c->h_out_pinned;
+  if (stats) *stats = c->last;
+  return RT_OK;
+}
 int rt_trace_counting(rt_ctx* c, int W, int H, float* out, rt_stats* stats) { return trace_host(c, W, H, out, stats, true); }
 
 int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* out, int counting, rt_stats* stats) {

@@ -130,6 +130,19 @@ enum : int {
   CNT_FAULT = 25,          // set by k_tail when a barrier gave up (reported as RT_ERR_DEVICE)
   CNT_TAILS = 32
 };
+// Compact per-frame statistics (uint64 each) that the last kernel of a frame writes to host-mapped memory, so that
+// reading a frame's counters needs no copy (a second device-to-host copy behind the pixel copy serialised the frames
+// that other contexts had in flight).
+enum StatSlot : int {
+  STAT_QUEUE0 = 0,        // rays that entered bounce queue 0 (survivors of the TLAS test in k_raygen)
+  STAT_SECONDARY = 1,     // sum of bounce queues 1..maxBounceCount
+  STAT_SHADOW = 2,
+  STAT_QUEUE1 = 3,        // the launch-strategy hint
+  STAT_FAULT = 4,
+  STAT_NODE_VISITS = 5, STAT_TRI_TESTS = 6, STAT_NODE_VISITS_SH = 7, STAT_TRI_TESTS_SH = 8,
+  STAT_DIAG = 9,          // 6 values
+  STAT_WORDS = 16
+};
 constexpr int CNT_WORKS = CNT_TAILS + N_QUEUES * N_SHARDS * CNT_STRIDE;
 constexpr int CNT_WORDS = CNT_WORKS + N_QUEUES * N_SHARDS * CNT_STRIDE;
 // tail (= number of entries) of shard `shard` of queue `queue`; chunk cursor of the launch that consumes it

@@ -35,8 +35,10 @@ struct FrameDev {
   float4* sample_color;        // per-sample tmpColor (rgb, 1), index = i*(rows*W) + ly*W + x
   uint32_t* counters;          // rt::CNT_* layout
   int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread
+  unsigned long long* stats_out;   // host-mapped StatSlot block, written by k_resolve (NULL: not wanted)
   uint32_t* hint;              // host-mapped word: size of bounce queue 1 (read by the host as a launch-strategy hint)
-  float4* out;                 // compact shard image (rows x W RGBA32F)
+  float4* out;                 // compact shard image (rows x W RGBA32F; rows x W RGBA8 when out_rgba8 is set)
+  int out_rgba8;
   uint32_t shard_cap;          // entries per queue shard (queues hold N_SHARDS * shard_cap rays)
   int width, height;           // full frame
   int rows;                    // rows rendered by this shard (compact)
