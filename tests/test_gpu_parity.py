@@ -465,6 +465,34 @@ def test_general_affine_and_masked_instances(ctx):
     assert np.array_equal(g, o) and not np.any(g["inst"] == 3) and np.any(g["inst"] == 2)
 
 
+def test_mirrored_and_sheared_instances(ctx):
+    """Instance transforms with negative determinant (a mirrored copy) and shear: hits are two-sided (instances are built
+    with TRIANGLE_FACING_CULL_DISABLE, src/main.cpp:545-546) and normals go through the inverse transpose, so images and
+    hit records must still equal the oracle's."""
+    paths = [os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj")]
+    mirror = np.array([[-1.2, 0.0, 0.0, -2.5], [0.0, 1.0, 0.0, 0.0], [0.0, 0.0, 0.8, 1.0]], np.float32).reshape(12)
+    shear = np.array([[1.0, 0.6, 0.0, 3.0], [0.0, 1.0, 0.3, -0.5], [0.2, 0.0, 1.0, 2.0]], np.float32).reshape(12)
+    both = np.array([[0.0, -1.0, 0.4, 0.0], [1.5, 0.0, 0.0, 3.0], [0.0, 0.2, -0.7, 5.0]], np.float32).reshape(12)
+    inst = np.zeros(3, scenes.INSTANCE_DTYPE)
+    inst[0] = host.make_instance(mirror, 0, 0)
+    inst[1] = host.make_instance(shear, 1, 1)
+    inst[2] = host.make_instance(both, 1, 0)
+    geom = host.SceneGeometry(paths)
+    for ctype, otype in ((1, 0), (2, 1), (0, 2)):
+        u = host.default_uniforms(max_bounce_count=4, samples_per_pixel=2, center_object_type=ctype, orbiting_object_type=otype,
+                                  orbiting_object_primitive_offset=geom.orbiting_primitive_offset, orbiting_object_vertex_offset=geom.orbiting_vertex_offset)
+        sp = scenes.ScenePair(paths, inst, u, sky=scenes.synthetic_skybox(64), ctx=ctx)
+        W, H = 200, 112
+        gpu, st = ctx.trace(W, H)
+        ref, rc = sp.orc.render(W, H)
+        check_image(gpu, ref)
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    rays = scenes.random_rays(5000, seed=11, target_radius=6.0)
+    g, _ = ctx.intersect(rays)
+    o = sp.orc.intersect(rays, use_bvh=False)
+    assert np.array_equal(g, o) and len(np.unique(g["inst"])) == 4   # three instances and the misses
+
+
 def test_cfg4_size_properties(ctx):
     """BASELINE config 4 size (3840x2160, depth 6): too big for the oracle, so size-independent properties only —
     determinism, alpha, ray bookkeeping, and 8 logical shards == the full frame bit for bit."""
