@@ -298,7 +298,6 @@ struct TraceArgs {
   float tmin;
   uint32_t rays_per_lane;      // device-side grid sizing (variant 0): blocks beyond total/(256*rays_per_lane) exit
   uint32_t min_blocks;
-  uint32_t* hint;              // host-mapped word that receives the queue size (bounce 1 only; NULL otherwise)
 };
 
 constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
@@ -349,7 +348,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     uint32_t total = 0;
 #pragma unroll
     for (int t = 0; t < N_SHARDS; t++) total += ld_cursor(a.tails + t * CNT_STRIDE);
-    if (a.hint && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.hint, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     uint32_t want = (total + 256u * a.rays_per_lane - 1u) / (256u * a.rays_per_lane);
     want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
     if (want < a.min_blocks) want = a.min_blocks;
@@ -1073,7 +1071,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body(a); }
 // small persistent grid alternates traversal and shading, separated by a grid-wide barrier, and leaves as
 // soon as a bounce queue is empty — the same test the reference loop makes per pixel.  The grid is small
 // (TAIL_BLOCKS) so that the tails of every frame in flight are co-resident and a barrier can always complete;
-// a frame with many secondary rays takes the per-bounce launches instead (rt_api decides from the last frame).
+// bounces whose queue held many rays in the previous frame of the context take the per-bounce launches on the full
+// grid first (rt_api decides where the tail starts from the queue sizes k_resolve reports).
 struct TailArgs {
   TraceArgs tr;          // closest-hit arguments; ray queue / cursors are set per bounce
   ShadeArgs sh;
@@ -1107,11 +1106,8 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
     uint32_t live = 0;
 #pragma unroll
     for (int k = 0; k < N_SHARDS; k++) live += ld_cursor(t.tr.counters + cnt_tail((int)b, k));
-    if (b == t.first_bounce && t.tr.hint && blockIdx.x == 0 && threadIdx.x == 0)
-      __hip_atomic_store(t.tr.hint, live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (live == 0 || ld_cursor(t.fault) != 0u) break;   // uniform over the grid: the queue is final since the last barrier
     TraceArgs a = t.tr;
-    a.hint = nullptr;
     a.ray_o = t.sh.f.ray_o[b & 1u]; a.ray_d = t.sh.f.ray_d[b & 1u];
     a.tails = t.tr.counters + cnt_tail((int)b, 0);
     a.work = t.tr.counters + cnt_work((int)b, 0);
@@ -1156,6 +1152,9 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
       s_q[t] = n;
     }
     __syncthreads();
+    // launch-strategy hint for the next frame of this context: the size of every bounce queue
+    if (f.hint && t >= 1u && t < (uint32_t)CNT_MAX_BOUNCES)
+      __hip_atomic_store(f.hint + t, (uint32_t)(s_q[t] > 0xFFFFFFFFull ? 0xFFFFFFFFull : s_q[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     auto put = [&](int slot, unsigned long long v) { __hip_atomic_store(f.stats_out + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
     auto cnt64 = [&](int word) { return (unsigned long long)ld_cursor(f.counters + word) | ((unsigned long long)ld_cursor(f.counters + word + 1) << 32); };
     if (t == 0) {
@@ -1221,7 +1220,6 @@ static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& 
 
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, f.counters, bounce, f.shard_cap, f.ovf_stack);
-  a.hint = bounce == 1 ? f.hint : nullptr;
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
@@ -1245,7 +1243,7 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
 void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TailArgs t{};
   t.tr = make_args(sc, f.counters, first_bounce, f.shard_cap, f.ovf_stack);
-  t.tr.hit_a = f.hit_a; t.tr.hit_inst = f.hit_inst; t.tr.hint = f.hint;
+  t.tr.hit_a = f.hit_a; t.tr.hit_inst = f.hit_inst;
   t.tr.rays_per_lane = 1u; t.tr.min_blocks = 8u;   // few rays: one per lane, the bounce costs one ray lifetime
   t.sh = ShadeArgs{sc, f, u, first_bounce};
   t.first_bounce = (uint32_t)first_bounce;

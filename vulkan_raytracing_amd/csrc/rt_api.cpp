@@ -110,8 +110,8 @@ struct rt_ctx {
   unsigned long long* h_stats = nullptr;   // pinned, device-visible StatSlot block written by k_resolve
   unsigned long long* d_stats = nullptr;
   bool last_empty = false;       // the last enqueued frame had no rows (nothing was launched)
-  uint32_t* h_hint = nullptr;    // pinned, device-visible word: size of bounce queue 1 in the most recent frame that reached
-  uint32_t* d_hint = nullptr;    // bounce 1 (written by the kernels; a speed hint only, never affects results)
+  uint32_t* h_hint = nullptr;    // pinned, device-visible array [CNT_MAX_BOUNCES]: bounce-queue sizes of the most recent finished
+  uint32_t* d_hint = nullptr;    // frame (written by k_resolve; a speed hint only, never affects results)
   int blas_builder = 1;          // 1: device LBVH (bvh_gpu.hip, default), 0: host binned-SAH
   bool timing = false;
   bool counting = false;
@@ -307,8 +307,8 @@ int ready_to_trace(rt_ctx* c) {
 int ensure_common(rt_ctx* c) {
   if (!c->d_counters) HIP_TRY(c, hipMalloc((void**)&c->d_counters, CNT_WORDS * sizeof(uint32_t)));
   if (!c->h_hint) {
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_hint, sizeof(uint32_t), hipHostMallocMapped));
-    *c->h_hint = 0xFFFFFFFFu;   // unknown: the first frame takes one launch per bounce
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_hint, CNT_MAX_BOUNCES * sizeof(uint32_t), hipHostMallocMapped));
+    for (int b = 0; b < CNT_MAX_BOUNCES; b++) c->h_hint[b] = 0xFFFFFFFFu;   // unknown: the first frame takes one launch per bounce
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_hint, c->h_hint, 0));
   }
   if (!c->h_stats) {
@@ -387,12 +387,17 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     Span frame_span(c, CAT_FRAME, s);
     HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s));
     { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
-    const bool use_tail = c->cfg.variant != 1 && u.max_bounce_count >= 1 &&
-                          (c->tail_mode == 2 || (c->tail_mode == 1 && *(volatile uint32_t*)c->h_hint <= TAIL_MAX_RAYS));
+    // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
+    // either strategy gives the same image); bounces before it run on the full persistent grid
+    uint32_t tail_start = 0xFFFFFFFFu;
+    if (c->cfg.variant != 1 && c->tail_mode == 2) tail_start = 1;
+    else if (c->cfg.variant != 1 && c->tail_mode == 1)
+      for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++)
+        if (((volatile uint32_t*)c->h_hint)[b] <= TAIL_MAX_RAYS) { tail_start = b; break; }
     for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
-      if (b == 1 && use_tail) {
+      if (b == tail_start) {
         // every later bounce in one launch (src/shader.rgen:84 loop), leaving as soon as a queue is empty
-        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, 1, c->counting, c->cfg, s);
+        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, s);
         break;
       }
       { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
@@ -425,7 +430,6 @@ int collect_stats(rt_ctx* c) {
   if (!c->last_empty) {
     st.rays_secondary = hs[STAT_SECONDARY];
     st.rays_shadow = hs[STAT_SHADOW];
-    *c->h_hint = (uint32_t)std::min<uint64_t>(hs[STAT_QUEUE1], 0xFFFFFFFFu);
     if (hs[STAT_FAULT] != 0) { c->frame_pending = false; return fail(c, RT_ERR_DEVICE, "k_tail: a grid barrier did not complete (frame discarded)"); }
     // rays that went through the closest-hit traversal kernel: primary rays that survived the TLAS
     // test fused into k_raygen (queue 0) plus every secondary ray

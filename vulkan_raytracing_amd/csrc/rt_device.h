@@ -118,7 +118,7 @@ constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounce
 constexpr int Q_SHADOW = CNT_MAX_BOUNCES;      // queue id of the shadow-ray queue
 constexpr int N_QUEUES = CNT_MAX_BOUNCES + 1;
 constexpr int TAIL_BLOCKS = 64;                // grid of k_tail: small enough that the tails of all frames in flight are co-resident
-constexpr uint32_t TAIL_MAX_RAYS = 65536;      // frames whose first secondary queue is larger take one launch per bounce
+constexpr uint32_t TAIL_MAX_RAYS = 65536;      // bounces whose queue was larger in the previous frame get their own full-grid launches
 enum : int {
   CNT_NODE_VISITS = 0,     // uint64: closest-hit kernel (counting builds only)
   CNT_TRI_TESTS = 2,       // uint64
@@ -137,7 +137,7 @@ enum StatSlot : int {
   STAT_QUEUE0 = 0,        // rays that entered bounce queue 0 (survivors of the TLAS test in k_raygen)
   STAT_SECONDARY = 1,     // sum of bounce queues 1..maxBounceCount
   STAT_SHADOW = 2,
-  STAT_QUEUE1 = 3,        // the launch-strategy hint
+  STAT_QUEUE1 = 3,        // size of bounce queue 1
   STAT_FAULT = 4,
   STAT_NODE_VISITS = 5, STAT_TRI_TESTS = 6, STAT_NODE_VISITS_SH = 7, STAT_TRI_TESTS_SH = 8,
   STAT_DIAG = 9,          // 6 values

@@ -36,7 +36,8 @@ struct FrameDev {
   uint32_t* counters;          // rt::CNT_* layout
   int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread
   unsigned long long* stats_out;   // host-mapped StatSlot block, written by k_resolve (NULL: not wanted)
-  uint32_t* hint;              // host-mapped word: size of bounce queue 1 (read by the host as a launch-strategy hint)
+  uint32_t* hint;              // host-mapped array [CNT_MAX_BOUNCES]: size of every bounce queue, written by k_resolve and
+                               // read by the host, unsynchronised, as the launch-strategy hint for the next frame
   float4* out;                 // compact shard image (rows x W RGBA32F; rows x W RGBA8 when out_rgba8 is set)
   int out_rgba8;
   uint32_t shard_cap;          // entries per queue shard (queues hold N_SHARDS * shard_cap rays)
