@@ -337,7 +337,7 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 
 template <int MODE, bool ANY, bool COUNT, bool WIDE>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
-  __shared__ int s_stack[4][STACK2_LDS][64];
+  __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
@@ -535,17 +535,51 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         else pop();
       }
     };
+    // The same visit without a branch, for the common case that the stack stays inside its LDS rows: the top of the
+    // stack is read while the node is still in flight (a pop then costs nothing on the dependent chain), the far child
+    // is written unconditionally (lanes that do not push write to the scratch row), and the next node is a chain of
+    // selects.  The visit is the unit of the kernel's dependent instruction chain, which is what bounds it.
+    typedef __attribute__((address_space(3))) volatile int lds_vint;   // volatile AND still an LDS pointer (ds_read/ds_write)
+    lds_vint* const stk_lds = (lds_vint*)stk;
+    auto fast_step = [&]() {
+      if (cur >= 0) {
+        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));
+        const uint4 Q0 = np[0], Q1 = np[1];
+        // volatile: the read has to be issued here, under the node fetch, not sunk into a branch after the box tests
+        const int top = stk_lds[(sp - 1) * 64];
+        const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
+        if (COUNT) cnt_nodes++;
+        float t0, t1;
+        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+        const bool both = h0 && h1, none = !(h0 || h1), swap = t1 < t0;
+        const uint32_t pm = 0u - (uint32_t)both;   // all ones when pushing
+        stk_lds[(((uint32_t)sp & pm) | ((uint32_t)STACK2_LDS & ~pm)) * 64u] = swap ? ch.x : ch.y;   // the far child: one store, no branch
+        const int one = h0 ? ch.x : ch.y;
+        cur = both ? (swap ? ch.y : ch.x) : (none ? top : one);
+        sp += (both ? 1 : 0) - (none ? 1 : 0);
+      }
+    };
 #ifdef RT_EXP_PHASE_DIAG   // experiment: diag = (outer passes, cycles inside the interior loop, wave cycles)
     const uint64_t ph_t0 = COUNT ? __builtin_readcyclecounter() : 0;
 #endif
+    constexpr int UNROLL = WIDE ? RT_WIDE_UNROLL : RT_INTERIOR_UNROLL;
     for (;;) {
       const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(cur >= 0));
       if (n_int == 0 || n_int < keep_going) break;
 #ifndef RT_EXP_PHASE_DIAG
       if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
 #endif
+      // fast visits need every stack they touch inside the LDS rows: sp - 1 >= 0 always holds for a live ray, and
+      // UNROLL pushes must fit below row STACK2_LDS
+      const bool deep = cur >= 0 && sp + UNROLL > STACK2_LDS;
+      if (!WIDE && __ballot(deep) == 0) {
 #pragma unroll
-      for (int r = 0; r < (WIDE ? RT_WIDE_UNROLL : RT_INTERIOR_UNROLL); r++) interior_step();
+        for (int r = 0; r < UNROLL; r++) fast_step();
+      } else {
+#pragma unroll
+        for (int r = 0; r < UNROLL; r++) interior_step();
+      }
     }
 #ifdef RT_EXP_PHASE_DIAG
     if (COUNT && lane == 0) { diag_iters++; diag_busy += __builtin_readcyclecounter() - ph_t0; }
