@@ -1189,16 +1189,22 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
     // launch-strategy hint for the next frame of this context: the size of every bounce queue
     if (f.hint && t >= 1u && t < (uint32_t)CNT_MAX_BOUNCES)
       __hip_atomic_store(f.hint + t, (uint32_t)(s_q[t] > 0xFFFFFFFFull ? 0xFFFFFFFFull : s_q[t]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    auto put = [&](int slot, unsigned long long v) { __hip_atomic_store(f.stats_out + slot, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    // every slot is written by its own thread: the stores cross PCIe and would cost ~0.3 us each one after another
     auto cnt64 = [&](int word) { return (unsigned long long)ld_cursor(f.counters + word) | ((unsigned long long)ld_cursor(f.counters + word + 1) << 32); };
-    if (t == 0) {
-      unsigned long long sec = 0;
-      for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) sec += s_q[b];
-      put(STAT_QUEUE0, s_q[0]); put(STAT_SECONDARY, sec); put(STAT_SHADOW, s_q[Q_SHADOW]); put(STAT_QUEUE1, s_q[1]);
-      put(STAT_FAULT, ld_cursor(f.counters + CNT_FAULT));
-      put(STAT_NODE_VISITS, cnt64(CNT_NODE_VISITS)); put(STAT_TRI_TESTS, cnt64(CNT_TRI_TESTS));
-      put(STAT_NODE_VISITS_SH, cnt64(CNT_NODE_VISITS_SH)); put(STAT_TRI_TESTS_SH, cnt64(CNT_TRI_TESTS_SH));
-      for (int k = 0; k < 3; k++) { put(STAT_DIAG + k, cnt64(CNT_DIAG + 2 * k)); put(STAT_DIAG + 3 + k, cnt64(CNT_DIAG_SH + 2 * k)); }
+    if (t < (uint32_t)STAT_WORDS) {
+      unsigned long long v = 0;
+      if (t == STAT_QUEUE0) v = s_q[0];
+      else if (t == STAT_SECONDARY) { for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) v += s_q[b]; }
+      else if (t == STAT_SHADOW) v = s_q[Q_SHADOW];
+      else if (t == STAT_QUEUE1) v = s_q[1];
+      else if (t == STAT_FAULT) v = ld_cursor(f.counters + CNT_FAULT);
+      else if (t == STAT_NODE_VISITS) v = cnt64(CNT_NODE_VISITS);
+      else if (t == STAT_TRI_TESTS) v = cnt64(CNT_TRI_TESTS);
+      else if (t == STAT_NODE_VISITS_SH) v = cnt64(CNT_NODE_VISITS_SH);
+      else if (t == STAT_TRI_TESTS_SH) v = cnt64(CNT_TRI_TESTS_SH);
+      else if (t >= STAT_DIAG && t < STAT_DIAG + 3) v = cnt64(CNT_DIAG + 2 * (int)(t - STAT_DIAG));
+      else if (t >= STAT_DIAG + 3 && t < STAT_DIAG + 6) v = cnt64(CNT_DIAG_SH + 2 * (int)(t - STAT_DIAG - 3));
+      __hip_atomic_store(f.stats_out + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 }
