@@ -501,31 +501,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       }
       if (cur >= 0) {   // idle lanes hold REF_DONE
         const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
-        uint4 Q0 = np[0], Q1 = np[1];
-#ifdef RT_EXP_DUP_LOADS   // sensitivity experiment: the same lines fetched again (L1 hits, address-unit load only)
-        {
-          const uint32_t z = a.shard_cap >> 31;   // 0 at run time, opaque to the compiler
-#pragma unroll
-          for (int e = 1; e <= RT_EXP_DUP_LOADS; e++) {
-            const uint4* dp = np + (size_t)z * 2u * e;
-            const uint4 D0 = dp[0], D1 = dp[1];
-            Q0.x |= D0.x & z; Q1.x |= D1.x & z;
-          }
-        }
-#endif
+        const uint4 Q0 = np[0], Q1 = np[1];
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
         const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
         const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
-#ifdef RT_EXP_EXTRA_VALU   // sensitivity experiment: a dependent chain of extra fmas per visit
-        {
-          float acc = t0;
-#pragma unroll
-          for (int e = 0; e < RT_EXP_EXTRA_VALU; e++) acc = __builtin_fmaf(acc, qs.x, qb.y);
-          if (acc == 12345.678f) t1 = t0;
-        }
-#endif
         if (h0 && h1) {
           const bool swap = t1 < t0;
           push(swap ? ch.x : ch.y);
@@ -707,30 +688,16 @@ __device__ __forceinline__ int quad_mini(int v) {
   return v;
 }
 
-// Slab test of the quad kernel: six v_fma_f32 evaluate the plane distances as t = plane*(1/d) + (-o/d).
-// (Deliberately NOT v_pk_fma_f32: packed f32 math issues far slower than two scalar fmas on gfx950 —
-// measured here as +45 % on the shadow kernel — and the file is built with -fno-slp-vectorize for the
-// same reason.)  The product o/d is rounded once per ray space, so an absolute slack proportional to
-// |o/d| joins the relative one; the test stays conservative, never canonical.
+// Ray space of the quad kernel (float boxes, sub-mul slab test).  An fma form (t = plane/d - o/d) was measured
+// 45 % slower on the any-hit kernel, and packed v_pk_fma_f32 slower still (the file is built with -fno-slp-vectorize).
 struct RaySpace {
   F3 id;   // 1/d
-  F3 n;    // -o/d
-  float abs_slack;
 };
 __device__ __forceinline__ RaySpace make_space(F3 o, F3 d) {
+  (void)o;
   RaySpace r;
   r.id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-  r.n = mk3(-(o.x * r.id.x), -(o.y * r.id.y), -(o.z * r.id.z));
-  r.abs_slack = 4e-7f * fmaxf(fmaxf(__builtin_fabsf(r.n.x), __builtin_fabsf(r.n.y)), __builtin_fabsf(r.n.z));
   return r;
-}
-__device__ __forceinline__ bool slab4(const float4 A, const float4 B, const RaySpace& rs, float tmin, float tlim, float& tn) {
-  const float x0 = __builtin_fmaf(A.x, rs.id.x, rs.n.x), x1 = __builtin_fmaf(A.w, rs.id.x, rs.n.x);
-  const float y0 = __builtin_fmaf(A.y, rs.id.y, rs.n.y), y1 = __builtin_fmaf(B.x, rs.id.y, rs.n.y);
-  const float z0 = __builtin_fmaf(A.z, rs.id.z, rs.n.z), z1 = __builtin_fmaf(B.y, rs.id.z, rs.n.z);
-  tn = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-  const float tf = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tlim));
-  return tn <= __builtin_fmaf(tf, 1.00002f, rs.abs_slack);
 }
 
 template <int MODE, bool ANY, bool COUNT>
@@ -841,26 +808,15 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
       const float4 A = cp[0], B = cp[1];
       if (COUNT) { if (sub == 0) cnt_nodes++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) diag_iters++; }
       float tn;
-#ifdef RT_EXP_FMA_SLAB
-      const bool hit = slab4(A, B, rs, tmin, best_t, tn);
-#else
       // sub-mul form: measured faster than the fma form on the any-hit kernel (0.76 vs 1.13 ms) and exact at o == plane
       const bool hit = slab(A.x, A.y, A.z, A.w, B.x, B.y, co, rs.id, tmin, best_t, tn);
-#endif
       const int ref = (int)__float_as_uint(B.z);
       // hit children of this quad: 4 bits of the wave ballot
-#ifdef RT_EXP_OLD_NH
-      const int nh_dummy = 0; (void)nh_dummy;
-#else
       const uint32_t qbits = (uint32_t)(__ballot(hit) >> quad_shift) & 0xFu;
       const int nh = __builtin_popcount(qbits);
-#endif
       const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | sub) : (KEY_MISS | sub);
       const uint32_t k1 = dpp_u<QP_ROT1>(key), k2 = dpp_u<QP_ROT2>(key), k3 = dpp_u<QP_ROT3>(key);
       const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
-#ifdef RT_EXP_OLD_NH
-      const int nh = (int)(k1 < KEY_MISS) + (int)(k2 < KEY_MISS) + (int)(k3 < KEY_MISS) + (int)hit;
-#endif
       const uint32_t nearest = quad_or((hit && rank == 0) ? (uint32_t)ref : 0u);
       if (hit && rank > 0) stk_ray[(sp + nh - 1 - rank) * 16] = ref;   // farthest child deepest
       if (nh == 0) { sp--; cur = stk_ray[sp * 16]; }
