@@ -254,6 +254,8 @@ def test_frames_in_flight_async_entry_points(ctx):
                 c.trace_async(W, H)
             with pytest.raises(RtError):
                 ring[0].trace_async(W, H)     # one pending frame per context
+            with pytest.raises(RtError):
+                ring[0].set_instances(sp.instances, update=True)   # the scene of a pending frame is not touched
             for c in ring:
                 img, st = c.trace_wait()
                 assert np.array_equal(img, ref)

@@ -297,6 +297,16 @@ SceneDev scene_dev(const rt_ctx* c) {
   return s;
 }
 
+int collect_stats(rt_ctx* c);
+
+// Scene-changing calls wait for the frame this context still has in flight (the reference waits on the frame's fence
+// before it touches the TLAS or the uniform buffer again, src/main.cpp:772-778).
+int quiesce(rt_ctx* c) {
+  if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "a frame submitted with rt_trace_async is pending: call rt_trace_wait first");
+  if (c->frame_pending) return collect_stats(c);
+  return RT_OK;
+}
+
 int ready_to_trace(rt_ctx* c) {
   if (!c->d_verts) return fail(c, RT_ERR_NOT_READY, "rt_upload_geometry has not been called");
   if (!c->tlas_valid) return fail(c, RT_ERR_NOT_READY, "rt_set_instances has not been called");
@@ -527,6 +537,7 @@ int rt_upload_geometry(rt_ctx* c, const float* verts6, size_t n_floats, const ui
                        const rt_mesh_range* ranges, int n_meshes) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!verts6 || !idx || !ranges || n_meshes <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "null geometry pointers or no meshes");
+  { int q = quiesce(c); if (q) return q; }
   if (n_floats % 6 != 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "vertex buffer must hold 6 floats per vertex");
   HIP_TRY(c, hipSetDevice(c->device));
   for (int m = 0; m < n_meshes; m++) {
@@ -555,6 +566,7 @@ int rt_upload_geometry(rt_ctx* c, const float* verts6, size_t n_floats, const ui
 int rt_build_blas(rt_ctx* c, int mesh) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
+  { int q = quiesce(c); if (q) return q; }
   Mesh& m = c->meshes[mesh];
   m.gpu_built = false;
   if (c->blas_builder == 1 && c->cfg.variant != 1 && m.range.prim_count >= 8) {
@@ -585,6 +597,7 @@ int rt_build_blas(rt_ctx* c, int mesh) {
 int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!inst || n <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "no instances");
+  { int q = quiesce(c); if (q) return q; }
   HIP_TRY(c, hipSetDevice(c->device));
   for (int i = 0; i < n; i++) {
     if (inst[i].mesh >= c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance references an unknown mesh");
@@ -647,6 +660,7 @@ int rt_set_skybox(rt_ctx* c, const uint8_t* const faces[6], int w, int h) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!faces || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad skybox arguments");
   for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RT_ERR_INVALID_ARGUMENT, "skybox face is NULL");
+  { int q = quiesce(c); if (q) return q; }
   HIP_TRY(c, hipSetDevice(c->device));
   const size_t face_bytes = (size_t)w * h * 4;
   if (c->d_sky) { HIP_TRY(c, hipFree(c->d_sky)); c->d_sky = nullptr; }
