@@ -234,3 +234,20 @@ def test_cfg1_cube_scene_render_and_shading_terms():
             assert np.allclose(img[py, px_, :3], exp, atol=5e-5), (px_, py)
             checked += 1
     assert checked >= 10 and hit.any()
+
+
+def test_oracle_frames_match_their_committed_hashes():
+    """The oracle's own regression goldens (tests/golden/oracle_images.json, written by make_oracle_images.py):
+    bit-identical frames and ray counts.  They pin the oracle to its own past, not to the reference."""
+    import importlib.util
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_images", os.path.join(here, "make_oracle_images.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "oracle_images.json")))
+    got = {name: mod.render_record(sp, W, H) for name, (sp, W, H) in mod.cases().items()}
+    assert set(got) == set(want)
+    for name in want:
+        assert got[name]["rays"] == want[name]["rays"], name
+        assert got[name]["sha256"] == want[name]["sha256"], name
