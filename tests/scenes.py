@@ -32,6 +32,7 @@ class ScenePair:
     """Oracle scene + (optionally) product context with identical inputs."""
 
     def __init__(self, obj_paths, instances, uniforms, sky=None, ctx=None):
+        self.geom_paths = list(obj_paths)
         self.geom = host.SceneGeometry(obj_paths)
         self.instances = np.ascontiguousarray(instances, INSTANCE_DTYPE)
         self.uniforms = uniforms

@@ -106,6 +106,24 @@ def test_cfg1_cube_scene_image(ctx):
     assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
 
 
+def test_frames_match_committed_golden_hashes(ctx):
+    """The HIP path against the committed fixtures (tests/golden/oracle_images.json: SHA-256 of frames the oracle
+    rendered, made by tests/golden/make_oracle_images.py): identical bytes, identical ray counts — no oracle run here."""
+    import hashlib
+    import importlib.util
+    import json
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_images", os.path.join(here, "make_oracle_images.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "oracle_images.json")))
+    for name, (sp, W, H) in mod.cases().items():
+        scenes.ScenePair(sp.geom_paths, sp.instances, sp.uniforms, sky=sp.sky, ctx=ctx)   # same inputs, uploaded to the GPU context
+        img, st = ctx.trace(W, H)
+        assert hashlib.sha256(np.ascontiguousarray(img, np.float32).tobytes()).hexdigest() == want[name]["sha256"], name
+        assert [st.rays_primary, st.rays_secondary, st.rays_shadow] == want[name]["rays"], name
+
+
 @pytest.mark.parametrize("center_type,orbit_type,max_bounce", [(1, 0, 1), (2, 0, 3), (1, 1, 5), (0, 2, 2)])
 def test_cfg2_teapot_cube_image(ctx, center_type, orbit_type, max_bounce):
     """BASELINE config 2 scene (teapot + orbiting cube) at reduced size; mirror, refractive, diffuse mixes."""
