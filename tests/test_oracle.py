@@ -251,3 +251,15 @@ def test_oracle_frames_match_their_committed_hashes():
     for name in want:
         assert got[name]["rays"] == want[name]["rays"], name
         assert got[name]["sha256"] == want[name]["sha256"], name
+
+
+def test_division_free_over_255_equals_ieee_division(tmp_path):
+    """kernels.hip computes x/255 in the cube-map filter with two fmas instead of an IEEE division; the oracle divides.
+    tools/check_div255.c proves both agree for every binary32 x in [0, 256] (exhaustive with stride 1); here every
+    61st value is checked so that the CPU suite stays fast."""
+    import subprocess
+    exe = str(tmp_path / "check_div255")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "check_div255.c")
+    subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm", "-lpthread"], check=True)
+    r = subprocess.run([exe, "61"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout

@@ -184,6 +184,17 @@ __device__ __forceinline__ bool tri_test(const float4 T0, const float4 T1, const
   return true;
 }
 
+// x / 255.0f without the ten-instruction IEEE division sequence: q = x*rc, one fma for the exact remainder, one fma
+// to correct q (rc = RN(1/255)).  The result equals the IEEE quotient — which is what the canonical definition and
+// the oracle use — for EVERY binary32 x in [0, 256]: proved exhaustively by tools/check_div255.c (1.13e9 values,
+// sampled in tests/test_oracle.py); the filter below only produces values in [0, 255].
+__device__ __forceinline__ float div255(float x) {
+  const float rc = 0x1.010102p-8f;   // 0x3b808081
+  const float q = x * rc;
+  const float r = __builtin_fmaf(-q, 255.0f, x);
+  return __builtin_fmaf(r, rc, q);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Cube-map lookup (LINEAR, CLAMP_TO_EDGE per face, RGBA8 UNORM) — same arithmetic as oracle sample_sky.
 __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
@@ -207,7 +218,7 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
   float ra = __builtin_fmaf((float)c10.x, wu, (float)c00.x * iu), rb = __builtin_fmaf((float)c11.x, wu, (float)c01.x * iu);
   float ga = __builtin_fmaf((float)c10.y, wu, (float)c00.y * iu), gb = __builtin_fmaf((float)c11.y, wu, (float)c01.y * iu);
   float ba = __builtin_fmaf((float)c10.z, wu, (float)c00.z * iu), bb = __builtin_fmaf((float)c11.z, wu, (float)c01.z * iu);
-  return mk3(__builtin_fmaf(rb, wv, ra * iv) / 255.0f, __builtin_fmaf(gb, wv, ga * iv) / 255.0f, __builtin_fmaf(bb, wv, ba * iv) / 255.0f);
+  return mk3(div255(__builtin_fmaf(rb, wv, ra * iv)), div255(__builtin_fmaf(gb, wv, ga * iv)), div255(__builtin_fmaf(bb, wv, ba * iv)));
 }
 
 // ------------------------------------------------------------------------------------------------
