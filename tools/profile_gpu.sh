@@ -1,12 +1,13 @@
 #!/bin/bash
 # Runs on the GPU box (through gpurun): kernel-trace stats and PMC traffic passes for bench.py.
-# Usage: tools/profile_gpu.sh <tag>      -> gpurun_out/prof_<tag>/...
+# Usage: tools/profile_gpu.sh <tag> [bench args]      -> gpurun_out/prof_<tag>/...
 set -o pipefail
 TAG=${1:-r01}
+shift
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python3 bench.py --no-cpu-baseline"   # the default command (60 steps, 3 frames in flight), minus the CPU leg
+BENCH="python3 bench.py --no-cpu-baseline $@"   # the default command (60 steps, 4 frames in flight), minus the CPU leg
 # 1) per-kernel time
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || { echo "kernel-trace failed"; tail -5 $OUT/trace.log; exit 1; }
 # 2) PMC passes (own runs, no tracing domains besides kernel-trace): FETCH_SIZE and WRITE_SIZE separately
