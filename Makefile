@@ -25,14 +25,14 @@ clean:
 .PHONY: all oracle clean resource-usage
 
 # host-side library (OBJ/MTL ingest, camera, animation, stand-in mesh, JPEG decode) — g++ only
-HOSTSRC := $(CSRC)/host_shim.cpp host/fly_camera.cpp host/standin.cpp $(wildcard host/jpeg_decode.cpp)
+HOSTSRC := $(CSRC)/host_shim.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp $(wildcard host/jpeg_decode.cpp)
 $(PKG)/librt_host.so: $(HOSTSRC) include/jpeg_decode.h include/rt_host.hpp include/obj_loader.h include/camera.h include/rt_vec.h include/config.h include/rt_api.h
-	g++ -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -o $@ $(HOSTSRC)
+	g++ -O2 -std=c++17 -fPIC -shared -pthread -Wall -Iinclude -o $@ $(HOSTSRC)
 all: $(PKG)/librt_host.so
 
 # headless C++ host (counterpart of the reference's main()); links the product library only
-rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so include/rt_host.hpp
-	g++ -O2 -std=c++17 -Wall -Iinclude -o $@ host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/jpeg_decode.cpp -L$(PKG) -lrt_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
+rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so include/rt_host.hpp
+	g++ -O2 -std=c++17 -pthread -Wall -Iinclude -o $@ host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp -L$(PKG) -lrt_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
 
 # kernel experiments: make exp EXP_NAME=<suffix> EXP_FLAGS="-DRT_EXP_..."  -> librt_mi355x_<suffix>.so (load with RT_LIB_VARIANT)
 exp:

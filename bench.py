@@ -34,7 +34,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-from vulkan_raytracing_amd import RtContext, host, tiling  # noqa: E402
+from vulkan_raytracing_amd import RtContext, host, tiling, workloads  # noqa: E402
 
 WIDTH, HEIGHT, MAX_BOUNCE, SPP = 1920, 1080, 3, 4   # BASELINE config 3 (the headline); --workload cfg4 / cfg5 change them
 WORKLOAD = "cfg3"
@@ -42,56 +42,29 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 RAY_BYTES, HIT_BYTES = 32, 20
 
 
-def ring_instances(n_inst, radius):
-    """cfg5: n instances of the orbiting mesh's BLAS on a ring about the origin (generalises M1 = T(0,0,5) of
-    src/main.cpp:1805-1808), all with customIndex 1, plus the center mesh as instance 0."""
-    from vulkan_raytracing_amd.api import INSTANCE_DTYPE
-    inst = np.zeros(n_inst + 1, INSTANCE_DTYPE)
-    inst[0] = host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)
-    for k in range(n_inst):
-        a = 2.0 * np.pi * k / n_inst
-        c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
-        # R_y(a) * T(0,0,radius): rotation then the translated offset
-        t = np.array([c, 0, s, s * radius, 0, 1, 0, 0, -s, 0, c, c * radius], np.float32)
-        inst[k + 1] = host.make_instance(t, 1, 1)
-    return inst
+_WL = {}
 
 
-_SCENE_CACHE = {}
-
-
-def build_scene(ctx, res):
+def workload(res, mesh):
     # host-side ingest (OBJ parse, JPEG decode) happens once per process; every context gets its own upload + BLAS/TLAS
-    if "geom" not in _SCENE_CACHE:
-        arm, arm_label = host.armadillo_path(res)
-        _SCENE_CACHE["geom"] = host.SceneGeometry([os.path.join(res, "teapot.obj"), arm])
-        _SCENE_CACHE["label"] = arm_label
-        _SCENE_CACHE["sky"] = host.load_skybox(os.path.join(res, "skybox_texture_sea"))
-    geom, arm_label = _SCENE_CACHE["geom"], _SCENE_CACHE["label"]
-    ctx.upload_geometry(geom.verts, geom.idx, geom.ranges)
-    anim = host.SceneAnimation()                      # t = 0: M0 = I, M1 = T(0,0,5) (src/main.cpp:1805-1808)
-    inst = ring_instances(16, 10.0) if WORKLOAD == "cfg5" else anim.instances((0, 1))
-    ctx.set_instances(inst)
-    u = host.default_uniforms(max_bounce_count=MAX_BOUNCE, samples_per_pixel=SPP, center_object_type=1, orbiting_object_type=0,
-                              orbiting_object_primitive_offset=geom.orbiting_primitive_offset,
-                              orbiting_object_vertex_offset=geom.orbiting_vertex_offset)
-    ctx.set_uniforms(u)
-    sky = _SCENE_CACHE["sky"]
-    ctx.set_skybox(sky)
-    return geom, inst, u, sky, arm_label
+    key = (WORKLOAD, mesh)
+    if key not in _WL:
+        _WL[key] = workloads.make(WORKLOAD, res, mesh=mesh)
+    return _WL[key]
 
 
-def cpu_baseline(geom, inst, u, sky, budget_s=12.0):
+def cpu_baseline(wl, budget_s=12.0):
     """The oracle (oracle/rt_oracle.cpp, kind "port") on this box's host cores: whole 1920x1080 frames of
     the same workload, repeated until about `budget_s` seconds of CPU work.  Checker code: used here ONLY
     as the reported CPU baseline, never by the product path.  Threads = the box's CPU share for one GPU
     (16) unless RT_CPU_THREADS says otherwise."""
     from oracle import oracle as orc
     S = orc.OracleScene()
+    geom, inst = wl.geometry, wl.instances
     S.set_geometry(geom.verts, geom.idx, geom.ranges)
     S.set_instances([inst[i].tobytes() for i in range(len(inst))])
-    S.set_uniforms(u.tobytes())
-    S.set_skybox(sky)
+    S.set_uniforms(wl.uniforms.tobytes())
+    S.set_skybox(wl.sky)
     avail = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
@@ -129,6 +102,9 @@ def main():
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
                     help="cfg3 (default, the headline): 1920x1080 depth 4; cfg4: 3840x2160 depth 6; cfg5: 16 instances of the armadillo BLAS, 1920x1080 depth 4")
+    ap.add_argument("--mesh", default="standin", choices=["limbs", "standin"],
+                    help="which stand-in replaces the missing resources/armadillo.obj: limbs = the non-star-shaped figure (default, "
+                         "the harder and more armadillo-like one), standin = the geodesic blob of round 1; ignored when the real file is supplied")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
                          "reassembly where only one GPU exists (its throughput is meaningless)")
@@ -174,15 +150,16 @@ def main():
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
-        host.armadillo_path(res)  # generate the stand-in once before the other ranks look for it
+        host.armadillo_path(res, kind=args.mesh)  # generate the stand-in once before the other ranks look for it
     if collective:
         dist.barrier()
+    wl = workload(res, args.mesh)
     # one context (scene replica, queues, counters) per frame in flight — the analogue of the reference's
     # per-swapchain-image command buffer, fence and semaphores (src/main.cpp:2597, 2740-2749)
     ctxs = []
     for _ in range(P):
         c = RtContext(local_rank)
-        geom, inst, u, sky, arm_label = build_scene(c, res)
+        wl.apply(c)
         if args.variant is not None:
             c.set_param("trace_variant", args.variant)
         for kv in args.param:
@@ -281,8 +258,7 @@ def main():
         result = {"metric": metric, "value": value, "unit": "Mrays/s",
                   "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": "BASELINE %s: teapot.obj mirror + %s diffuse%s, skybox_texture_sea, %dx%d, maxBounceCount %d (depth %d) + shadow rays, spp %d"
-                                         % (WORKLOAD, arm_label, " x16 instances on a ring (one BLAS, two-level BVH)" if WORKLOAD == "cfg5" else "", WIDTH, HEIGHT, MAX_BOUNCE, MAX_BOUNCE + 1, SPP),
+                  "config": {"workload": wl.describe(), "mesh": wl.mesh_label,
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
                              "ray_classes": "value counts every traceRayEXT-equivalent: primary + secondary (bounce) + shadow rays; 'secondary' in the metric string means both",
                              "parallelism": "interleaved %d-row bands over %d GPU(s), scene replicated, one RCCL gather per frame, %d frames in flight per GPU" % (band, n, P),
@@ -338,7 +314,7 @@ def main():
                 fh.write(b"PF4\n%d %d\n-1.0\n" % (WIDTH, HEIGHT))
                 fh.write(img[::-1].astype("<f4").tobytes())
         if n == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(geom, inst, u, sky)
+            result["cpu_baseline"] = cpu_baseline(wl)
         else:
             result["cpu_baseline"] = None
         sys.stdout.flush()

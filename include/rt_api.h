@@ -103,6 +103,9 @@ typedef struct rt_stats {
   float ms_tail;             /* k_tail: bounces 1..maxBounceCount in one launch (0 when the per-bounce launches ran) */
   uint32_t bvh_node_bytes;   /* S_node, S_tri of the roofline formula */
   uint32_t bvh_tri_bytes;
+  uint32_t tail_faults;      /* frames of this context that were rendered again with per-bounce launches because a k_tail grid
+                                barrier gave up (its workgroups were not co-resident); the context stays off k_tail afterwards */
+  uint32_t reserved0;
 } rt_stats;
 
 /* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */
@@ -183,6 +186,10 @@ int rt_trace_counting(rt_ctx* ctx, int width, int height, float* out_rgba32f_hos
  * children inside parents, quantized boxes containing float boxes, depth and stack bounds).  out[8] = nodes, leaves,
  * depth, max leaf size, BVH4 nodes, BVH4 stack need, violations, triangles reached.  0 = all invariants hold. */
 int rt_debug_check_builders(const float* verts6, size_t n_floats, const uint32_t* idx, size_t n_idx, uint64_t* out8);
+/* Host-only view of the launch/allocation sizing rules (needs no GPU): out2[0] = workgroups of the k_tail grid on a device
+ * of n_cu compute units holding resident_per_cu of them each (0 = k_tail is not used), out2[1] = int32 elements of the
+ * spill-stack allocation for that grid, a traversal grid of trace_blocks workgroups and ovf_stride entries per thread. */
+int rt_debug_sizing(int n_cu, int resident_per_cu, int trace_blocks, uint32_t ovf_stride, uint64_t* out2);
 
 /* Message of the last failing call on this context (or of rt_create when ctx==NULL). */
 const char* rt_last_error(const rt_ctx* ctx);

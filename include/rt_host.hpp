@@ -153,6 +153,10 @@ struct SceneAnimation {
 // 10 n^2 + 2 vertices; n = 132 -> 348 480 triangles, the Stanford armadillo has 345 944) displaced by
 // a fixed sum of lobes, radius about 3, smooth per-vertex normals, faces written `f a//a b//b c//c`.
 void writeArmadilloStandin(const std::string& objPath, int frequency = 132);
+// Second stand-in, deliberately NOT star-shaped (host/standin_limbs.cpp): a standing figure with limbs, claws, ears and
+// a curled tail as ONE implicit surface meshed by surface nets on a resolution^3 grid; returns the triangle count
+// (resolution 306 -> 345 168 triangles, 172 565 vertices, the size of the Stanford armadillo).
+size_t writeArmadilloLimbs(const std::string& objPath, int resolution = 306);
 
 // RAII wrapper over the C ABI; every failure throws (src/main.cpp:138-147 behaviour).
 class Renderer {

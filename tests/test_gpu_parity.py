@@ -78,9 +78,13 @@ def test_intersect_edge_cases(ctx):
     assert np.array_equal(g, sp.orc.intersect(odd, use_bvh=False))
 
 
-def test_intersect_armadillo_standin_vs_oracle_bvh(ctx):
+MESHES = ("standin", "limbs")   # the star-shaped geodesic blob of round 1 and the non-star-shaped figure with limbs
+
+
+@pytest.mark.parametrize("mesh", MESHES)
+def test_intersect_armadillo_standin_vs_oracle_bvh(ctx, mesh):
     """346 k-triangle class mesh: GPU BVH traversal vs the oracle's own (independent) BVH."""
-    arm, label = host.armadillo_path(RES)
+    arm, label = host.armadillo_path(RES, kind=mesh)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 3, 1, ctx=ctx)
     rays = scenes.random_rays(30000, seed=21, target_radius=5.0)
     g, st = ctx.intersect(rays, counting=True)
@@ -137,9 +141,10 @@ def test_cfg2_teapot_cube_image(ctx, center_type, orbit_type, max_bounce):
     assert st.rays_secondary > 0
 
 
-def test_cfg3_armadillo_image_small(ctx):
+@pytest.mark.parametrize("mesh", MESHES)
+def test_cfg3_armadillo_image_small(ctx, mesh):
     """BASELINE config 3 scene (teapot mirror + armadillo stand-in diffuse, depth 4 + shadow rays), 240x136."""
-    arm, _ = host.armadillo_path(RES)
+    arm, _ = host.armadillo_path(RES, kind=mesh)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 3, 4, sky=scenes.synthetic_skybox(128), ctx=ctx)
     W, H = 240, 136
     gpu, st = ctx.trace(W, H)
@@ -219,11 +224,12 @@ def test_sample_counts_that_do_not_fill_a_workgroup(ctx, spp):
     assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
 
 
-def test_full_size_properties_cfg3(ctx):
+@pytest.mark.parametrize("mesh", MESHES)
+def test_full_size_properties_cfg3(ctx, mesh):
     """At BASELINE config 3 size (1920x1080, depth 4, spp 4) the oracle is too slow for a full
     frame, so check size-independent properties: determinism across runs, alpha == 1, ray
     bookkeeping, an oracle-rendered band of rows, and sharded == unsharded on a band subset."""
-    arm, _ = host.armadillo_path(RES)
+    arm, _ = host.armadillo_path(RES, kind=mesh)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 3, 4, sky=scenes.synthetic_skybox(256), ctx=ctx)
     W, H = 1920, 1080
     a, st = ctx.trace(W, H)
@@ -567,5 +573,157 @@ def test_device_builders_on_degenerate_soup(ctx, algo, monkeypatch, tmp_path):
         sh = rays.copy(); sh[:, 7] = 7.0
         ga, _ = c2.intersect(sh, any_hit=True)
         assert np.array_equal(ga["inst"] >= 0, sp.orc.intersect(sh, use_bvh=False)["inst"] >= 0)
+    finally:
+        c2.close()
+
+
+# ---- BASELINE configurations on their real workloads (vulkan_raytracing_amd/workloads.py is what bench.py runs) ---------------
+class _OracleTarget:
+    """adapts the oracle scene to Workload.apply()"""
+
+    def __init__(self):
+        from oracle import oracle
+        self.orc = oracle.OracleScene()
+
+    def upload_geometry(self, verts, idx, ranges):
+        self.orc.set_geometry(verts, idx, ranges)
+
+    def set_instances(self, inst):
+        self.orc.set_instances([inst[i].tobytes() for i in range(len(inst))])
+
+    def set_uniforms(self, u):
+        self.orc.set_uniforms(u.tobytes())
+
+    def set_skybox(self, faces):
+        self.orc.set_skybox(faces)
+
+
+def _logical_shards_equal_full(ctx, W, H, n, full):
+    import torch
+    rows_max = tiling.max_shard_rows(H, tiling.BAND_ROWS, n)
+    shards, total = [], 0
+    for s in range(n):
+        buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+        ctx.trace_shard(W, H, tiling.BAND_ROWS, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+        st = ctx.stats()
+        total += st.rays_total
+        torch.cuda.synchronize()
+        shards.append(buf.cpu().numpy())
+    assert np.array_equal(tiling.assemble(shards, H, W, tiling.BAND_ROWS), full)
+    return total
+
+
+@pytest.mark.parametrize("mesh", MESHES)
+def test_cfg5_armadillo_x16_full_size(ctx, mesh):
+    """BASELINE config 5 ON ITS WORKLOAD: 16 instances of the armadillo-class BLAS (stand-in, 345-348 k triangles) on a ring
+    + the mirror teapot, 1920x1080, depth 4, spp 4 — exactly what `bench.py --workload cfg5` times.  Too big for a full
+    oracle frame, so: determinism, alpha, ray bookkeeping with NON-ZERO bounce rays (the mirror teapot is in view and
+    reflects the ring: the bounce rays walk the two-level BVH), 8 logical shards == the full frame bit for bit, and an
+    oracle-rendered 8-row band through the teapot."""
+    from vulkan_raytracing_amd import workloads
+    wl = workloads.make("cfg5", RES, mesh=mesh)
+    wl.apply(ctx)
+    W, H = wl.width, wl.height
+    assert (W, H) == (1920, 1080) and len(wl.instances) == 17 and int(wl.uniforms[0]["max_bounce_count"]) == 3
+    a, st = ctx.trace(W, H)
+    b, st2 = ctx.trace(W, H)
+    assert np.array_equal(a, b)
+    assert np.all(a[..., 3] == 1.0) and np.isfinite(a).all()
+    assert st.rays_primary == W * H * 4 and st.rays_total == st2.rays_total
+    assert st.rays_secondary > 10000, st.rays_secondary      # depth 4 is not vacuous: the teapot mirror is visible
+    assert st.rays_shadow > W * H                            # the diffuse ring fills much of the frame
+    assert _logical_shards_equal_full(ctx, W, H, 8, a) == st.rays_total
+    tgt = _OracleTarget()
+    wl.apply(tgt)
+    # the band with the most bounce rays: rows where the teapot (mirror, RGB far from the green diffuse shading) sits
+    y0 = 8 * int(np.argmax([np.abs(a[y:y + 8, 700:1220, 0] - a[y:y + 8, 700:1220, 1]).sum() for y in range(0, H - 8, 8)]))
+    part, rc = tgt.orc.render(W, H, y0=y0, y1=y0 + 8)
+    d = np.abs(a[y0:y0 + 8] - part[y0:y0 + 8]).max(axis=2)
+    assert (d <= TOL).mean() >= FRAC and (d == 0).mean() >= FRAC, (y0, float((d <= TOL).mean()), float((d == 0).mean()))
+    assert int(rc[1]) > 0    # the oracle traced bounce rays in that band as well
+
+
+def test_cfg2_full_size_real_skybox(ctx):
+    """BASELINE config 2 ON ITS WORKLOAD: teapot (mirror) + cube, the real skybox_texture_test JPEG faces (2048^2, decoded by
+    host/jpeg_decode.cpp), 1280x720, depth 2, spp 4 — the whole frame against the oracle."""
+    from vulkan_raytracing_amd import workloads
+    wl = workloads.make("cfg2", RES)
+    wl.apply(ctx)
+    assert wl.sky[0].shape == (2048, 2048, 4)
+    W, H = wl.width, wl.height
+    assert (W, H) == (1280, 720)
+    gpu, st = ctx.trace(W, H)
+    tgt = _OracleTarget()
+    wl.apply(tgt)
+    ref, rc = tgt.orc.render(W, H)
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    assert st.rays_secondary > 0 and st.rays_shadow > 0
+    # most of the frame is sky: the real texture must actually have been sampled
+    assert len(np.unique(gpu[::8, ::8, :3].reshape(-1, 3), axis=0)) > 2000
+
+
+@pytest.mark.parametrize("mesh", MESHES)
+def test_cfg3_reduced_size_real_sea_skybox(ctx, mesh):
+    """BASELINE config 3 scene with its real skybox_texture_sea faces at 480x270 against the oracle (the full-size test
+    above uses a synthetic cube map to keep the oracle band cheap)."""
+    from vulkan_raytracing_amd import workloads
+    wl = workloads.make("cfg3", RES, mesh=mesh)
+    wl.apply(ctx)
+    W, H = 480, 270
+    gpu, st = ctx.trace(W, H)
+    tgt = _OracleTarget()
+    wl.apply(tgt)
+    ref, rc = tgt.orc.render(W, H)
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    assert st.rays_secondary > 0 and st.rays_shadow > 0
+
+
+def test_single_instance_scene_is_not_traversed_twice(ctx):
+    """A one-instance TLAS has a synthetic root with one real child.  The absent child is an inverted box that no ray
+    enters (it used to be a copy of its sibling, which made every ray walk the instance twice): node visits and triangle
+    tests of the one-instance scene must not exceed those of the same scene plus a second, invisible instance."""
+    cube = os.path.join(RES, "cube.obj")
+    geom = host.SceneGeometry([cube])
+    one = np.zeros(1, scenes.INSTANCE_DTYPE)
+    one[0] = host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)
+    two = np.zeros(2, scenes.INSTANCE_DTYPE)
+    two[0] = one[0]
+    far = host.make_instance(np.array([1, 0, 0, 500, 0, 1, 0, 500, 0, 0, 1, 500], np.float32), 0, 0)
+    far["custom_index_and_mask"] = 0     # mask 0
+    two[1] = far
+    rays = scenes.random_rays(4096, seed=9, origin_radius=8.0, target_radius=1.0)
+    ctx.upload_geometry(geom.verts, geom.idx, geom.ranges)
+    ctx.set_uniforms(host.default_uniforms(max_bounce_count=0, samples_per_pixel=1))
+    ctx.set_instances(one)
+    g1, s1 = ctx.intersect(rays, counting=True)
+    ctx.set_instances(two)
+    g2, s2 = ctx.intersect(rays, counting=True)
+    assert np.array_equal(g1, g2) and (g1["inst"] == 0).mean() > 0.5
+    assert s1.tri_tests == s2.tri_tests and s1.node_visits <= s2.node_visits
+    assert s1.tri_tests <= 12 * len(rays)
+
+
+def test_tail_fault_falls_back_to_per_bounce_launches(ctx):
+    """If a k_tail grid barrier gives up, the frame is rendered again with one launch per bounce and kernel instead of
+    being discarded, and the context stays off k_tail (rt_stats.tail_faults counts it).  The fault is injected on the
+    host side (rt_set_param debug_force_tail_fault): a real one needs another process squatting on the GPU."""
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 2, 1, 12, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.5)
+    W, H = 160, 96
+    c2 = RtContext(0)
+    try:
+        scenes.ScenePair(sp.geom_paths, sp.instances, sp.uniforms, sky=sp.sky, ctx=c2)
+        c2.set_param("tail_kernel", 2)
+        good, st0 = c2.trace(W, H)
+        assert st0.tail_faults == 0
+        c2.set_param("debug_force_tail_fault", 1)
+        again, st1 = c2.trace(W, H)
+        assert st1.tail_faults == 1 and np.array_equal(again, good)
+        assert (st1.rays_primary, st1.rays_secondary, st1.rays_shadow) == (st0.rays_primary, st0.rays_secondary, st0.rays_shadow)
+        c2.set_param("debug_force_tail_fault", 1)
+        c2.trace_async(W, H)
+        img, st2 = c2.trace_wait()
+        assert np.array_equal(img, good) and st2.tail_faults == 1   # the context was already off k_tail: nothing to re-render
     finally:
         c2.close()

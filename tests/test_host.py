@@ -25,7 +25,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = api.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 2
+    assert L.rt_abi_version() == 3
     assert L.rt_shard_rows(1080, 8, 0, 8) == tiling.shard_rows(1080, 8, 0, 8)
 
 
@@ -165,6 +165,75 @@ def test_standin_mesh_is_deterministic_and_closed(tmp_path):
     p2 = str(tmp_path / "s2.obj")
     host.hlib().rth_write_armadillo_standin(p2.encode(), 6)
     assert open(p).read() == open(p2).read()
+
+
+def test_limbs_standin_is_closed_deterministic_and_not_star_shaped(tmp_path):
+    """host/standin_limbs.cpp: the second armadillo stand-in (implicit figure + surface nets).  Closed manifold, unit normals
+    that point out of the surface, deterministic, the size of the Stanford armadillo at the default resolution — and, unlike
+    the geodesic blob, NOT star-shaped: rays cross many surfaces."""
+    from oracle import oracle
+    p = str(tmp_path / "l.obj")
+    n = host.hlib().rth_write_armadillo_limbs(p.encode(), 96)
+    s = host.SceneGeometry([p])
+    assert n == s.ranges[0][2] and 25000 < n < 45000
+    tri = s.idx.reshape(-1, 3)
+    e = np.sort(np.concatenate([tri[:, [0, 1]], tri[:, [1, 2]], tri[:, [2, 0]]]), axis=1)
+    _, counts = np.unique(e, axis=0, return_counts=True)
+    # closed: every edge is shared by an even number of triangles — two, except for the handful of edges where two
+    # sheets of the surface pinch inside one grid cell (surface nets keeps those as 4-fold edges)
+    assert np.all(counts % 2 == 0) and (counts == 2).mean() > 0.995
+    v = s.verts.reshape(-1, 6)
+    assert np.allclose(np.linalg.norm(v[:, 3:6], axis=1), 1.0, atol=1e-3)
+    # winding agrees with the vertex normals (both point out of the figure)
+    fn = np.cross(v[tri[:, 1], :3] - v[tri[:, 0], :3], v[tri[:, 2], :3] - v[tri[:, 0], :3])
+    assert (np.sum(fn * v[tri[:, 0], 3:6], axis=1) > 0).mean() > 0.995
+    p2 = str(tmp_path / "l2.obj")
+    host.hlib().rth_write_armadillo_limbs(p2.encode(), 96)
+    assert open(p).read() == open(p2).read()
+    # surface crossings along rays through the figure (closest hit, advance, repeat): a star-shaped blob gives 2 on
+    # rays through its centre; the figure gives 4 and more where limbs, claws and tail overlap
+    S = oracle.OracleScene()
+    S.set_geometry(s.verts, s.idx, s.ranges)
+    inst = np.zeros(1, scenes.INSTANCE_DTYPE)
+    inst[0] = host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)
+    S.set_instances([inst[0].tobytes()])
+    rays = scenes.random_rays(3000, seed=3, origin_radius=12.0, target_radius=2.5)
+    crossings = np.zeros(len(rays), int)
+    live = np.ones(len(rays), bool)
+    for _ in range(12):
+        h = S.intersect(rays, use_bvh=True)
+        hit = live & (h["inst"] >= 0)
+        crossings += hit
+        live = hit
+        rays[:, 3] = np.where(hit, h["t"] + 1e-3, rays[:, 3])
+    assert crossings.max() >= 6 and (crossings >= 4).mean() > 0.10
+    assert np.all(crossings % 2 == 0)                           # closed surface: every ray that enters leaves
+    # the default resolution gives a mesh of the Stanford armadillo's size (345 944 triangles)
+    arm, label = host.armadillo_path(os.path.join(ROOT, "resources"), kind="limbs")
+    assert "345168 triangles" in label
+
+
+def test_sizing_rules_of_the_tail_kernel_and_spill_stacks():
+    """rt_debug_sizing: the k_tail grid never exceeds 1/16 of the workgroups a device can hold (16 frame slots in flight
+    stay co-resident), is a multiple of the 8 queue shards, is 0 (= not used) on a device too small for that; the spill-stack
+    allocation covers the LARGER of the traversal grid and the tail grid."""
+    L = api.lib()
+
+    def sizing(n_cu, per_cu, trace_blocks, stride):
+        out = np.zeros(2, np.uint64)
+        assert L.rt_debug_sizing(n_cu, per_cu, trace_blocks, stride, out.ctypes.data_as(ctypes.c_void_p)) == 0
+        return int(out[0]), int(out[1])
+
+    assert sizing(256, 5, 1024, 40) == (64, 1024 * 256 * 40)     # MI355X: 64 workgroups, stacks for the 1024-block traversal grid
+    assert sizing(256, 2, 1024, 40)[0] == 32
+    assert sizing(32, 4, 128, 40) == (8, 128 * 256 * 40)         # a 32-CU partition
+    assert sizing(8, 4, 8, 48) == (0, 8 * 256 * 48)              # too small: k_tail off
+    g, elems = sizing(64, 8, 16, 40)                             # traversal grid smaller than the tail grid
+    assert g == 32 and elems == 32 * 256 * 40
+    for n_cu in (1, 7, 20, 64, 80, 256, 304):
+        for per_cu in (0, 1, 3, 5, 8):
+            g, _ = sizing(n_cu, per_cu, 4 * n_cu, 40)
+            assert g % 8 == 0 and g <= 64 and g * 16 <= n_cu * per_cu
 
 
 def test_band_sharding_covers_frame_once():

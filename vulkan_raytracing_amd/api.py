@@ -23,7 +23,7 @@ class RtStats(C.Structure):
                 ("ms_frame", C.c_float), ("ms_raygen", C.c_float), ("ms_trace_closest", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_shade", C.c_float), ("ms_resolve", C.c_float),
                 ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32), ("timed_frames", C.c_uint32), ("ms_tail", C.c_float),
-                ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32)]
+                ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32), ("tail_faults", C.c_uint32), ("reserved0", C.c_uint32)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k == "diag" else getattr(self, k)) for k, _ in self._fields_}
@@ -35,7 +35,7 @@ class RtStats(C.Structure):
 
 EXPORTS = ["rt_create", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
            "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
-           "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_last_error", "rt_device_info", "rt_abi_version"]
+           "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_debug_sizing", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
 _LIB = None
 
@@ -64,6 +64,7 @@ def lib():
         L.rt_set_timing.argtypes = [vp, C.c_int]
         L.rt_set_param.argtypes = [vp, C.c_char_p, C.c_int]
         L.rt_debug_check_builders.argtypes = [vp, C.c_size_t, vp, C.c_size_t, vp]
+        L.rt_debug_sizing.argtypes = [C.c_int, C.c_int, C.c_int, C.c_uint32, vp]
         L.rt_intersect.argtypes = [vp, C.c_size_t, vp, C.c_int, vp, C.c_int, C.POINTER(RtStats)]
         L.rt_last_error.argtypes = [vp]
         L.rt_last_error.restype = C.c_char_p

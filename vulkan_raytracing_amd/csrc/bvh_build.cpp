@@ -334,12 +334,17 @@ void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3
     const BvhNode& n = bvh.nodes[i];
     float c0[6] = {n.a[0], n.a[1], n.a[2], n.a[3], n.c[0], n.c[1]}, c1[6] = {n.b[0], n.b[1], n.b[2], n.b[3], n.c[2], n.c[3]};
     int32_t r0 = n.child0, r1 = n.child1;
-    if (!valid(c1)) { memcpy(c1, c0, sizeof(c0)); r1 = r0; }
-    if (!valid(c0)) { memcpy(c0, c1, sizeof(c1)); r0 = r1; }
+    const bool v0 = valid(c0), v1 = valid(c1);
+    // The absent child of a synthetic single-child root (one-instance TLAS, single-leaf BLAS) gets an INVERTED box
+    // (lower plane 0xFFFF, upper plane 0): no ray can enter it, so the sibling is never visited twice.  Its link
+    // repeats the sibling's so that every link in the array stays a valid reference for the tree walkers.
+    const uint32_t kNever = 0x0000FFFFu;
+    if (!v1) r1 = r0;
+    if (!v0) r0 = r1;
     BvhNodeQ q{};
     for (int k = 0; k < 3; k++) {
-      q.w[k] = qdn(c0[2 * k], k) | (qup(c0[2 * k + 1], k) << 16);
-      q.w[3 + k] = qdn(c1[2 * k], k) | (qup(c1[2 * k + 1], k) << 16);
+      q.w[k] = v0 ? (qdn(c0[2 * k], k) | (qup(c0[2 * k + 1], k) << 16)) : kNever;
+      q.w[3 + k] = v1 ? (qdn(c1[2 * k], k) | (qup(c1[2 * k + 1], k) << 16)) : kNever;
     }
     q.child0 = r0; q.child1 = r1;
     out[i] = q;

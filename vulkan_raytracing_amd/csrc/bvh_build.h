@@ -52,7 +52,7 @@ void collapse_bvh4(const BuiltBvh& b2, bool area_driven, bool direct_ids, Bvh4& 
 void refit_bvh4(const BuiltBvh& b2, Bvh4& b4);
 
 // 32-byte quantized form of bvh.nodes (rt_device.h BvhNodeQ).  q_lo/q_scale receive the dequantisation
-// of the tree's bounds.  A missing child (synthetic root of a one-leaf tree) becomes a copy of its sibling.
+// of the tree's bounds.  A missing child (synthetic root of a one-leaf tree) becomes an inverted box no ray can enter; its link repeats the sibling's.
 void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]);
 
 // 4-ary records (rt_device.h WideNodeQ) of `count` linked quantized nodes: out[i] holds the grandchildren of

@@ -393,10 +393,16 @@ int build_blas_gpu(const float* d_verts6, const uint32_t* d_idx, uint32_t n, hip
   int *parent_internal = nullptr, *parent_leaf = nullptr;
   float* qparams = nullptr;
   void* tmp = nullptr;
+  bool done = false;   // set once the results in `out` are complete: until then cleanup() frees them as well
   auto cleanup = [&]() {
     for (void* p : {(void*)tri_boxes, (void*)node_boxes, (void*)cbounds, (void*)keys, (void*)keys2, (void*)vals, (void*)vals2, (void*)flags, (void*)children,
                     (void*)ranges, (void*)parent_internal, (void*)parent_leaf, (void*)qparams, tmp})
       if (p) hipFree(p);
+    if (!done) {
+      if (out.nodes) hipFree(out.nodes);
+      if (out.tris) hipFree(out.tris);
+      out.nodes = nullptr; out.tris = nullptr;
+    }
   };
   const uint32_t nb = (n + 255u) / 256u;
   GB_TRY(hipMalloc((void**)&tri_boxes, n * sizeof(Box)));
@@ -466,6 +472,7 @@ int build_blas_gpu(const float* d_verts6, const uint32_t* d_idx, uint32_t n, hip
     PL_TRY(hipGetLastError());
     for (int k = 0; k < 3; k++) { out.q_lo[k] = h2[k]; out.q_scale[k] = h2[3 + k]; out.bounds_lo[k] = h2[6 + k]; out.bounds_hi[k] = h2[9 + k]; }
     out.n_nodes = n - 1; out.n_tris = n;
+    done = true;
     cleanup2(); cleanup();
     return 0;
 #undef PL_TRY
@@ -490,10 +497,8 @@ int build_blas_gpu(const float* d_verts6, const uint32_t* d_idx, uint32_t n, hip
   GB_TRY(hipGetLastError());
   for (int k = 0; k < 3; k++) { out.q_lo[k] = h[k]; out.q_scale[k] = h[3 + k]; out.bounds_lo[k] = h[6 + k]; out.bounds_hi[k] = h[9 + k]; }
   out.n_nodes = n - 1; out.n_tris = n;
-  BvhNodeQ* keep_nodes = out.nodes; float4* keep_tris = out.tris;
-  out.nodes = nullptr; out.tris = nullptr;   // cleanup() must not free the results
+  done = true;
   cleanup();
-  out.nodes = keep_nodes; out.tris = keep_tris;
   return 0;
 }
 

@@ -33,6 +33,10 @@ int rth_write_armadillo_standin(const char* path, int frequency) {
   try { rthost::writeArmadilloStandin(path, frequency); return 0; } catch (...) { return 1; }
 }
 
+long long rth_write_armadillo_limbs(const char* path, int resolution) {
+  try { return (long long)rthost::writeArmadilloLimbs(path, resolution); } catch (...) { return -1; }
+}
+
 void rth_default_uniforms(rt_uniforms* u) { *u = rthost::defaultUniforms(); }
 void rth_make_instance(const float* transform12, uint32_t objIndex, uint64_t mesh, rt_instance* out) { *out = rthost::createInstance(transform12, objIndex, mesh); }
 

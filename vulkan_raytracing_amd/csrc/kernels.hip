@@ -1071,7 +1071,8 @@ __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body(a); }
 // times; one launch per bounce and kernel would be 2 x 63 nearly empty launches (or host polls).  Here a
 // small persistent grid alternates traversal and shading, separated by a grid-wide barrier, and leaves as
 // soon as a bounce queue is empty — the same test the reference loop makes per pixel.  The grid is small
-// (TAIL_BLOCKS) so that the tails of every frame in flight are co-resident and a barrier can always complete;
+// (rt::tail_grid(): at most TAIL_BLOCKS, and never more than 1/MAX_TAILS_IN_FLIGHT of the workgroups the device can
+// hold) so that the tails of every frame in flight are co-resident and a barrier can always complete;
 // bounces whose queue held many rays in the previous frame of the context take the per-bounce launches on the full
 // grid first (rt_api decides where the tail starts from the queue sizes k_resolve reports).
 struct TailArgs {
@@ -1114,10 +1115,14 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
     a.work = t.tr.counters + cnt_work((int)b, 0);
     trace_body<MODE_CLOSEST, false, COUNT, WIDE>(a);
     grid_barrier(t.barrier, t.fault, phase);
+    // A barrier that gave up means some workgroup may still be tracing: its hit records are not final, so nobody may
+    // shade them.  Every workgroup leaves as soon as it sees the flag (the host re-renders the frame without k_tail).
+    if (ld_cursor(t.fault) != 0u) return;
     ShadeArgs sh = t.sh;
     sh.bounce = (int)b;
     shade_body(sh);
     grid_barrier(t.barrier, t.fault, phase);
+    if (ld_cursor(t.fault) != 0u) return;
   }
 }
 
@@ -1247,7 +1252,13 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
   else launch_trace<MODE_RAW, false>(a, counting, cfg, s);
 }
 
-void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+int tail_blocks_per_cu() {
+  int n = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tail<false, false>, 256, 0) != hipSuccess) return 0;
+  return n;
+}
+
+void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s) {
   TailArgs t{};
   t.tr = make_args(sc, f.counters, first_bounce, f.shard_cap, f.ovf_stack);
   t.tr.hit_a = f.hit_a; t.tr.hit_inst = f.hit_inst;
@@ -1255,7 +1266,7 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
   t.sh = ShadeArgs{sc, f, u, first_bounce};
   t.first_bounce = (uint32_t)first_bounce;
   t.barrier = f.counters + CNT_BARRIER; t.fault = f.counters + CNT_FAULT;
-  const dim3 g(TAIL_BLOCKS), b(256);
+  const dim3 g((unsigned)tail_blocks), b(256);
   if (cfg.variant == 2) {
     if (counting) hipLaunchKernelGGL((k_tail<true, true>), g, b, 0, s, t);
     else hipLaunchKernelGGL((k_tail<false, true>), g, b, 0, s, t);

@@ -72,6 +72,7 @@ struct rt_ctx {
   WideNodeQ* d_wide = nullptr;      // 4-ary records of the same trees, same numbering as d_blas_nodes
   std::vector<WideNodeQ> h_wide;
   uint32_t ovf_stride = STACK_OVF, ovf_alloc_stride = 0;
+  int ovf_alloc_blocks = 0;
   float4* d_tris = nullptr;
   size_t n_blas_nodes = 0, n_tris = 0;
 
@@ -106,6 +107,7 @@ struct rt_ctx {
   uint32_t* d_counters = nullptr;
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
+  int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped at rt_create so that MAX_TAILS_IN_FLIGHT of them are always co-resident
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
   unsigned long long* h_stats = nullptr;   // pinned, device-visible StatSlot block written by k_resolve
   unsigned long long* d_stats = nullptr;
@@ -122,6 +124,11 @@ struct rt_ctx {
   rt_stats last{};
   bool frame_pending = false;
   hipStream_t frame_stream = nullptr;
+  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; } last_frame{};
+  bool tail_disabled = false;    // a k_tail barrier gave up once: this context keeps to per-bounce launches from then on
+  bool frame_rerendered = false; // collect_stats rendered the pending frame again (after a k_tail fault): copies of it are stale
+  uint32_t tail_faults = 0;
+  bool debug_force_tail_fault = false;   // rt_set_param "debug_force_tail_fault": treat the next k_tail frame as faulted (tests the fallback)
   uint32_t last_max_bounce = 0;
   uint64_t last_primary = 0;
 };
@@ -177,6 +184,25 @@ Aabb instance_world_box(const float o2w[12], const Aabb& b) {
   for (int k = 0; k < 3; k++) { w.lo[k] -= pad; w.hi[k] += pad; }
   return w;
 }
+
+}  // namespace
+
+// Sizing rules with no device dependence (unit-tested on the CPU through rt_debug_sizing).
+// Spill-stack elements: one area of `stride` entries per thread of the larger of the two persistent grids.
+size_t rt::ovf_elems(int trace_blocks, int tail_blocks, uint32_t stride) {
+  return (size_t)std::max(trace_blocks, tail_blocks) * 256u * (size_t)stride;
+}
+// Grid of k_tail.  Its workgroups spin in a grid barrier, so every k_tail that can be in flight at once (one per frame
+// slot, up to MAX_TAILS_IN_FLIGHT on a GPU) must be co-resident: resident capacity / MAX_TAILS_IN_FLIGHT, a multiple of
+// N_SHARDS, at most TAIL_BLOCKS.  0 = the device is too small for the tail kernel (per-bounce launches are used).
+int rt::tail_grid(int n_cu, int resident_blocks_per_cu) {
+  const long cap = (long)n_cu * std::max(0, resident_blocks_per_cu) / MAX_TAILS_IN_FLIGHT;
+  long g = std::min<long>(TAIL_BLOCKS, cap);
+  g -= g % N_SHARDS;
+  return g >= N_SHARDS ? (int)g : 0;
+}
+
+namespace {
 
 int link_blas(rt_ctx* c) {
   // concatenate every built mesh into one node array / one packet array with global references
@@ -326,10 +352,11 @@ int ensure_common(rt_ctx* c) {
     memset(c->h_stats, 0, STAT_WORDS * sizeof(unsigned long long));
     HIP_TRY(c, hipHostGetDevicePointer((void**)&c->d_stats, c->h_stats, 0));
   }
-  if (c->d_ovf && c->ovf_alloc_stride < c->ovf_stride) { HIP_TRY(c, hipFree(c->d_ovf)); c->d_ovf = nullptr; }
+  if (c->d_ovf && (c->ovf_alloc_stride < c->ovf_stride || c->ovf_alloc_blocks < std::max(c->cfg.trace_blocks, c->tail_blocks))) { HIP_TRY(c, hipFree(c->d_ovf)); c->d_ovf = nullptr; }
   if (!c->d_ovf) {
-    HIP_TRY(c, hipMalloc((void**)&c->d_ovf, (size_t)c->cfg.trace_blocks * 256 * c->ovf_stride * sizeof(int32_t)));
-    c->ovf_alloc_stride = c->ovf_stride;
+    // one spill area per persistent thread of the LARGER grid: k_trace runs cfg.trace_blocks workgroups, k_tail tail_blocks
+    HIP_TRY(c, hipMalloc((void**)&c->d_ovf, ovf_elems(c->cfg.trace_blocks, c->tail_blocks, c->ovf_stride) * sizeof(int32_t)));
+    c->ovf_alloc_stride = c->ovf_stride; c->ovf_alloc_blocks = std::max(c->cfg.trace_blocks, c->tail_blocks);
   }
   return RT_OK;
 }
@@ -364,8 +391,9 @@ struct Span {
   }
 };
 
-int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, float4* d_out, hipStream_t s) {
+int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, float4* d_out, hipStream_t s, bool no_tail = false) {
   const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
+  c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting};
   const UniformsDev& u = c->uni;
   if (u.samples_per_pixel == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "samplesPerPixel must be >= 1");
   if (u.max_bounce_count + 2 > (uint32_t)CNT_MAX_BOUNCES) return fail(c, RT_ERR_INVALID_ARGUMENT, "maxBounceCount too large (max 69)");
@@ -400,14 +428,15 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
     // either strategy gives the same image); bounces before it run on the full persistent grid
     uint32_t tail_start = 0xFFFFFFFFu;
-    if (c->cfg.variant != 1 && c->tail_mode == 2) tail_start = 1;
-    else if (c->cfg.variant != 1 && c->tail_mode == 1)
+    const bool tail_ok = c->cfg.variant != 1 && c->tail_blocks > 0 && !no_tail && !c->tail_disabled;
+    if (tail_ok && c->tail_mode == 2) tail_start = 1;
+    else if (tail_ok && c->tail_mode == 1)
       for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++)
         if (((volatile uint32_t*)c->h_hint)[b] <= TAIL_MAX_RAYS) { tail_start = b; break; }
     for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
       if (b == tail_start) {
         // every later bounce in one launch (src/shader.rgen:84 loop), leaving as soon as a queue is empty
-        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, s);
+        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, c->tail_blocks, s);
         break;
       }
       { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
@@ -440,7 +469,22 @@ int collect_stats(rt_ctx* c) {
   if (!c->last_empty) {
     st.rays_secondary = hs[STAT_SECONDARY];
     st.rays_shadow = hs[STAT_SHADOW];
-    if (hs[STAT_FAULT] != 0) { c->frame_pending = false; return fail(c, RT_ERR_DEVICE, "k_tail: a grid barrier did not complete (frame discarded)"); }
+    if (hs[STAT_FAULT] != 0 || (c->debug_force_tail_fault && !c->tail_disabled)) {
+      // A grid barrier of k_tail gave up (its workgroups were not co-resident: another process on the GPU, a partition
+      // smaller than the occupancy query promised).  The frame is incomplete: render it again with one launch per bounce
+      // and kernel, and keep this context off k_tail from now on.
+      c->debug_force_tail_fault = false;
+      c->tail_faults++; c->tail_disabled = true;
+      const rt_ctx::LastFrame lf = c->last_frame;
+      const bool counting = c->counting;
+      c->counting = lf.counting;
+      c->ev_used = 0; c->spans.clear(); c->timed_frames = 0;
+      int r = enqueue_frame(c, lf.W, lf.H, lf.band_rows, lf.shard, lf.n_shards, lf.d_out, c->frame_stream, true);
+      c->counting = counting;
+      if (r) { c->frame_pending = false; return r; }
+      c->frame_rerendered = true;
+      return collect_stats(c);
+    }
     // rays that went through the closest-hit traversal kernel: primary rays that survived the TLAS
     // test fused into k_raygen (queue 0) plus every secondary ray
     st.closest_rays = hs[STAT_QUEUE0] + st.rays_secondary;
@@ -469,6 +513,7 @@ int collect_stats(rt_ctx* c) {
     st.launches_trace_closest /= c->timed_frames; st.launches_total /= c->timed_frames;
   }
   st.timed_frames = c->timed_frames;
+  st.tail_faults = c->tail_faults;
   c->ev_used = 0; c->spans.clear(); c->timed_frames = 0;
   c->last = st;
   c->frame_pending = false;
@@ -480,7 +525,7 @@ int collect_stats(rt_ctx* c) {
 // ================================================================================================
 extern "C" {
 
-int rt_abi_version(void) { return 2; }   // 2: rt_trace_async / rt_trace_wait, rt_stats::ms_tail
+int rt_abi_version(void) { return 3; }   // 2: rt_trace_async / rt_trace_wait, rt_stats::ms_tail; 3: rt_stats::tail_faults, rt_debug_sizing
 
 int rt_create(rt_ctx** out_ctx, int device_id) {
   if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
@@ -507,6 +552,7 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
+  c->tail_blocks = tail_grid(c->n_cu, tail_blocks_per_cu());   // 0: device too small for k_tail's co-residency guarantee
   if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TRACE_VARIANT")) { const int v = atoi(env); c->cfg.variant = (v >= 0 && v <= 2) ? v : 0; }
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
@@ -710,7 +756,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   }
   if (k == "trace_blocks_per_cu") {
     if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
-    if (c->d_ovf && value * c->n_cu > c->cfg.trace_blocks) { hipFree(c->d_ovf); c->d_ovf = nullptr; }
+    { int q = quiesce(c); if (q) return q; }   // the spill stacks are re-sized by the next frame (ensure_common)
     c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
   }
   if (k == "output_rgba8") {
@@ -719,6 +765,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     c->out_rgba8 = value != 0; return RT_OK;
   }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
+  if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
   if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); c->blas_builder = value; return RT_OK; }
   if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
   if (k == "trace_min_blocks") { if (value < 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_min_blocks must be >= 8"); c->cfg.min_blocks = value; return RT_OK; }
@@ -801,6 +848,16 @@ int rt_debug_check_builders(const float* verts6, size_t n_floats, const uint32_t
   return violations ? RT_ERR_INVALID_ARGUMENT : RT_OK;
 }
 
+// Host-only view of the sizing rules (no device needed): out[0] = grid of k_tail for a device with n_cu compute units that
+// can hold resident_per_cu of its workgroups each (0 = k_tail unusable), out[1] = int32 elements of the spill-stack
+// allocation for that grid, a traversal grid of trace_blocks and ovf_stride entries per thread.
+int rt_debug_sizing(int n_cu, int resident_per_cu, int trace_blocks, uint32_t ovf_stride, uint64_t* out) {
+  if (!out || n_cu <= 0 || trace_blocks <= 0) return RT_ERR_INVALID_ARGUMENT;
+  const int g = tail_grid(n_cu, resident_per_cu);
+  out[0] = (uint64_t)g; out[1] = (uint64_t)ovf_elems(trace_blocks, g, ovf_stride);
+  return RT_OK;
+}
+
 int rt_set_timing(rt_ctx* c, int enabled) { if (!c) return RT_ERR_INVALID_ARGUMENT; c->timing = enabled != 0; return RT_OK; }
 
 int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t out_capacity_bytes, void* hip_stream) {
@@ -808,11 +865,14 @@ int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shar
   if (W <= 0 || H <= 0 || band_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !d_out)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace_shard arguments");
   if (!c->have_uni) return fail(c, RT_ERR_NOT_READY, "rt_set_uniforms has not been called");
+  if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "a frame submitted with rt_trace_async is pending: call rt_trace_wait first");
   HIP_TRY(c, hipSetDevice(c->device));
   int r = ready_to_trace(c); if (r) return r;
   const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
   if ((size_t)rows * W * (c->out_rgba8 ? 4 : 16) > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for this shard");
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  // one set of queues and counters per context: a frame on another stream must not start while the previous one runs
+  if (c->frame_pending && c->frame_stream != s) { int q = collect_stats(c); if (q) return q; }
   return enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
 }
 
@@ -835,6 +895,7 @@ static int trace_host(rt_ctx* c, int W, int H, float* out, rt_stats* stats, bool
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (W <= 0 || H <= 0 || !out) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace arguments");
   HIP_TRY(c, hipSetDevice(c->device));
+  { int q = quiesce(c); if (q) return q; }
   const size_t px = (size_t)W * H;
   if (px > c->out_capacity) {
     if (c->d_out_own) HIP_TRY(c, hipFree(c->d_out_own));
@@ -874,6 +935,7 @@ int rt_trace_async(rt_ctx* c, int W, int H) {
     HIP_TRY(c, hipHostMalloc((void**)&c->h_out_pinned, px * sizeof(float4), hipHostMallocDefault));
     c->pinned_capacity = px;
   }
+  if (c->frame_pending) { int q = collect_stats(c); if (q) return q; }   // d_out_own may still be written by an rt_trace_shard frame
   int r = rt_trace_shard(c, W, H, H, 0, 1, c->d_out_own, px * sizeof(float4), nullptr);
   if (r) return r;
   HIP_TRY(c, hipMemcpyAsync(c->h_out_pinned, c->d_out_own, px * (c->out_rgba8 ? 4 : sizeof(float4)), hipMemcpyDeviceToHost, c->stream));
@@ -888,7 +950,10 @@ int rt_trace_wait(rt_ctx* c, const void** pixels, rt_stats* stats) {
   if (!c->async_pending) return fail(c, RT_ERR_NOT_READY, "rt_trace_wait without rt_trace_async");
   HIP_TRY(c, hipSetDevice(c->device));
   c->async_pending = false;
+  c->frame_rerendered = false;
   int r = collect_stats(c); if (r) return r;          // waits for the frame's kernels
+  if (c->frame_rerendered)   // the copy enqueued by rt_trace_async took the discarded frame
+    HIP_TRY(c, hipMemcpyAsync(c->h_out_pinned, c->d_out_own, (size_t)c->async_w * c->async_h * (c->out_rgba8 ? 4 : sizeof(float4)), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(c, hipStreamSynchronize(c->stream));        // ... and for the copy behind them
   if (pixels) *pixels = c->h_out_pinned;
   if (stats) *stats = c->last;
@@ -901,6 +966,7 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
   if ((!rays8 || !out) && n) return fail(c, RT_ERR_INVALID_ARGUMENT, "null ray/hit pointers");
   if (n >= 0xFFFFFF00ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "too many rays for one call");
   HIP_TRY(c, hipSetDevice(c->device));
+  { int q = quiesce(c); if (q) return q; }   // the counters and spill stacks below are the pending frame's
   int r = ready_to_trace(c); if (r) return r;
   r = ensure_common(c); if (r) return r;
   if (stats) memset(stats, 0, sizeof(*stats));
@@ -912,6 +978,11 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
     hd[i] = make_float4(p[4], p[5], p[6], p[7]);
   }
   float4 *d_o = nullptr, *d_d = nullptr; HitRec* d_h = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  struct Guard {   // every exit path below releases the temporaries
+    float4 *&o, *&d; HitRec*& h; hipEvent_t &a, &b;
+    ~Guard() { if (o) hipFree(o); if (d) hipFree(d); if (h) hipFree(h); if (a) hipEventDestroy(a); if (b) hipEventDestroy(b); }
+  } guard{d_o, d_d, d_h, e0, e1};
   HIP_TRY(c, hipMalloc((void**)&d_o, n * sizeof(float4)));
   HIP_TRY(c, hipMalloc((void**)&d_d, n * sizeof(float4)));
   HIP_TRY(c, hipMalloc((void**)&d_h, n * sizeof(HitRec)));
@@ -920,7 +991,7 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
   HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), c->stream));
   uint32_t n32 = (uint32_t)n;
   HIP_TRY(c, hipMemcpyAsync(c->d_counters + cnt_tail(0, 0), &n32, sizeof(n32), hipMemcpyHostToDevice, c->stream));
-  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
   hipEventRecord(e0, c->stream);
   launch_trace_raw(scene_dev(c), d_o, d_d, d_h, n32, c->d_ovf, c->d_counters, any_hit != 0, counting != 0, c->cfg, c->stream);
   hipEventRecord(e1, c->stream);
@@ -937,8 +1008,6 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
     stats->closest_rays = any_hit ? 0 : n; stats->rays_shadow = any_hit ? n : 0;
     stats->bvh_node_bytes = c->cfg.variant == 1 ? sizeof(Bvh4Node) : c->cfg.variant == 2 ? sizeof(WideNodeQ) : sizeof(BvhNodeQ); stats->bvh_tri_bytes = sizeof(TriPacket);
   }
-  hipEventDestroy(e0); hipEventDestroy(e1);
-  hipFree(d_o); hipFree(d_d); hipFree(d_h);
   return RT_OK;
 }
 

@@ -117,7 +117,8 @@ constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: 
 constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounceCount <= 69)
 constexpr int Q_SHADOW = CNT_MAX_BOUNCES;      // queue id of the shadow-ray queue
 constexpr int N_QUEUES = CNT_MAX_BOUNCES + 1;
-constexpr int TAIL_BLOCKS = 64;                // grid of k_tail: small enough that the tails of all frames in flight are co-resident
+constexpr int TAIL_BLOCKS = 64;                // largest grid of k_tail (rt_api clamps it to the device: tail_grid())
+constexpr int MAX_TAILS_IN_FLIGHT = 16;        // k_tail launches (frame slots) that must be co-resident on one GPU at any time
 constexpr uint32_t TAIL_MAX_RAYS = 65536;      // bounces whose queue was larger in the previous frame get their own full-grid launches
 enum : int {
   CNT_NODE_VISITS = 0,     // uint64: closest-hit kernel (counting builds only)

@@ -58,7 +58,7 @@ size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
-void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
+void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
@@ -68,5 +68,10 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
                       int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s);
 
 int trace_threads_per_block();
+// resident workgroups of k_tail per CU (occupancy query; <= 0 on failure)
+int tail_blocks_per_cu();
+// host-only sizing rules (rt_api.cpp)
+size_t ovf_elems(int trace_blocks, int tail_blocks, uint32_t stride);
+int tail_grid(int n_cu, int resident_blocks_per_cu);
 
 }  // namespace rt

@@ -30,6 +30,8 @@ def hlib():
             getattr(L, fn).argtypes = [vp]
             getattr(L, fn).restype = rt
         L.rth_write_armadillo_standin.argtypes = [C.c_char_p, C.c_int]
+        L.rth_write_armadillo_limbs.argtypes = [C.c_char_p, C.c_int]
+        L.rth_write_armadillo_limbs.restype = C.c_longlong
         L.rth_default_uniforms.argtypes = [vp]
         L.rth_make_instance.argtypes = [vp, C.c_uint32, C.c_uint64, vp]
         L.rth_anim_init.argtypes = [vp]
@@ -77,14 +79,34 @@ class SceneGeometry:
             L.rth_scene_free(h)
 
 
-def armadillo_path(resources_dir, cache_dir=None, frequency=132):
-    """resources/armadillo.obj if the user supplied it, else the generated stand-in (named as such)."""
+LIMBS_RESOLUTION = 306
+
+
+def _obj_triangle_count(path):
+    """the generators write '# ... N triangles' on the first line"""
+    with open(path) as fh:
+        head = fh.readline()
+    try:
+        return int(head.strip().split()[-2])
+    except Exception:
+        return -1
+
+
+def armadillo_path(resources_dir, cache_dir=None, frequency=132, kind="standin"):
+    """resources/armadillo.obj if the user supplied it, else a generated stand-in, named as such:
+    kind "standin" = the geodesic blob of host/standin.cpp (star-shaped: easy for a BVH),
+    kind "limbs"   = the implicit figure of host/standin_limbs.cpp (limbs, claws, concavities: hard)."""
     real = os.path.join(resources_dir, "armadillo.obj")
     if os.path.exists(real):
         return real, "armadillo.obj (user supplied)"
     cache_dir = cache_dir or os.path.join(resources_dir, "generated")
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, "armadillo_standin_f%d.obj" % frequency)
+    if kind == "limbs":
+        path = os.path.join(cache_dir, "armadillo_limbs_r%d.obj" % LIMBS_RESOLUTION)
+    elif kind == "standin":
+        path = os.path.join(cache_dir, "armadillo_standin_f%d.obj" % frequency)
+    else:
+        raise ValueError("unknown stand-in kind " + kind)
     mtl = os.path.join(resources_dir, "armadillo.mtl")
     if os.path.exists(mtl) and not os.path.exists(os.path.join(cache_dir, "armadillo.mtl")):
         import shutil
@@ -93,9 +115,14 @@ def armadillo_path(resources_dir, cache_dir=None, frequency=132):
         os.replace(tmp_mtl, os.path.join(cache_dir, "armadillo.mtl"))
     if not os.path.exists(path):
         tmp = path + ".tmp%d" % os.getpid()
-        if hlib().rth_write_armadillo_standin(os.fsencode(tmp), frequency) != 0:
+        if kind == "limbs":
+            if hlib().rth_write_armadillo_limbs(os.fsencode(tmp), LIMBS_RESOLUTION) < 0:
+                raise RuntimeError("limbs stand-in generation failed")
+        elif hlib().rth_write_armadillo_standin(os.fsencode(tmp), frequency) != 0:
             raise RuntimeError("stand-in generation failed")
         os.replace(tmp, path)
+    if kind == "limbs":
+        return path, "armadillo LIMBS STAND-IN (implicit figure, surface nets r=%d, %d triangles)" % (LIMBS_RESOLUTION, _obj_triangle_count(path))
     return path, "armadillo STAND-IN (geodesic f=%d, %d triangles)" % (frequency, 20 * frequency * frequency)
 
 
