@@ -41,6 +41,8 @@ def lib():
         L.orc_invert_affine.argtypes = [C.c_void_p, C.c_void_p]
         L.orc_sample_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_tri_test.argtypes = [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
+        L.orc_bounce_step.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
         L.orc_primary_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
         _LIB = L
     return _LIB
@@ -116,6 +118,21 @@ class OracleScene:
         o = np.zeros(3, np.float32)
         self.L.orc_sample_sky(self.h, _ptr(d), _ptr(o))
         return o
+
+    def bounce_step(self, od6, sample_index, hits):
+        """replays recorded bounces through the renderer's own per-bounce code; returns (n, 28) floats (see orc_bounce_step)"""
+        od6 = np.ascontiguousarray(od6, np.float32).reshape(-1, 6)
+        si = np.ascontiguousarray(sample_index, np.uint32)
+        hits = np.ascontiguousarray(hits, HIT_DTYPE)
+        out = np.zeros((len(od6), 28), np.float32)
+        assert self.L.orc_bounce_step(self.h, len(od6), _ptr(od6), _ptr(si), _ptr(hits), _ptr(out)) == 0
+        return out
+
+    def render_pixels(self, W, H, xy, use_bvh=True):
+        xy = np.ascontiguousarray(xy, np.uint32).reshape(-1, 2)
+        out = np.zeros((len(xy), 4), np.float32)
+        assert self.L.orc_render_pixels(self.h, W, H, len(xy), _ptr(xy), _ptr(out), int(use_bvh)) == 0
+        return out
 
     def primary_ray(self, px, py, W, H, i):
         o = np.zeros(6, np.float32)

@@ -20,13 +20,22 @@
 //   closest hit with tmin < t < tmax, no culling, opaque; any-hit terminate for shadow rays;
 //   ray transformed per instance by inverse(objectToWorld) without renormalising (t preserved).
 //
-// PARITY STATUS: "parity unpinned" for images — the reference holds no tests, golden images or
-// runnable CPU path for this stage.  What IS pinned by reference artefacts:
-//   * every numeric shader constant, against the OpConstant words of the reference's own
-//     shaders/*.spv (tests/golden/spv_constants.json);
-//   * the geometry ingest (a1-a4), against the reference's vendored tiny_obj_loader.h compiled
-//     in place (oracle/_ref, tests/golden/ingest_*.json);
+// PARITY STATUS.  The reference holds no tests, golden images or runnable CPU path for this stage, and its
+// traversal lives in the Vulkan driver.  What pins this restatement to reference-held artefacts:
+//   * the SHADING CODE ITSELF: tests/golden/spirv_fixtures.npz holds ~15 000 bounce-loop iterations and ~3 200 pixels that
+//     the reference's own compiled shaders (shaders/shader.rgen.spv, shader.rchit.spv, both miss modules) produced under
+//     the interpreter oracle/spirv_interp.py (the binaries are read as data; only traversal, the inverse instance
+//     transform and the cube sampler are bound to this file).  tests/test_oracle.py replays every record through
+//     jitter_hash / primary ray, closest_hit_attributes and bounce_step below: control flow identical, values within
+//     1e-5 (lit colour 2e-5).  This pins loop bounds, the material switch, operand order, offsets, signs and constants;
+//   * every numeric shader constant, against the OpConstant words of the same binaries (tests/golden/spv_constants.json);
+//   * the geometry ingest (a1-a4) and JPEG decode (a20), against the reference's vendored tiny_obj_loader.h / stb_image.h
+//     compiled in place (oracle/_ref, tests/golden/ingest_*.json);
 //   * the analytic known answers of SURVEY.md Appendix B.
+// Still "parity unpinned" because nothing in the reference states them: what the DRIVER does — BVH traversal order and
+// tie-breaking among equal t, the exact ray/triangle arithmetic, cube-map filtering — and the GLSL built-ins' precision
+// (sin, pow, normalize, dot: the canonical forms below are one admissible choice; pow(0.9,i) and pow(x,100) are
+// evaluated by repeated multiplication, within 100 ulp of the correctly rounded value).
 //
 // CANONICAL ARITHMETIC.  GLSL leaves the precision of sin/pow/normalize and FMA contraction to
 // the implementation, so no two Vulkan drivers produce identical bits.  The oracle fixes ONE
@@ -434,6 +443,67 @@ static inline float pow100(float x) {
 
 struct RayCounts { uint64_t primary = 0, secondary = 0, shadow = 0; };
 
+// One iteration of the bounce loop AFTER traceRayEXT has returned (src/shader.rgen:89-177), split from the loop so that
+// recorded (ray, hit) pairs — tests/golden/spirv_fixtures.npz, produced by interpreting the reference's own shader.rgen.spv /
+// shader.rchit.spv — can be replayed through exactly the code the renderer runs.
+enum StepKind { STEP_SKY = 0, STEP_BACKFACE = 1, STEP_SHADOW = 2, STEP_CONTINUE = 3 };
+struct Step {
+  int kind;
+  V3 P, N; int objectIndex;      // payload written by rchit (valid unless STEP_SKY)
+  V3 sky;                        // STEP_SKY: tmpColor = texture(...)                        (src/shader.rgen:90-94)
+  V3 so, sl; float stmax;        // STEP_SHADOW: the shadow ray                              (src/shader.rgen:107-112)
+  V3 lit;                        // STEP_SHADOW: tmpColor if the shadow ray reports no occluder (src/shader.rgen:114-129)
+  V3 no, nd;                     // STEP_CONTINUE: next rayOrigin / rayDirection             (src/shader.rgen:132-165)
+};
+static const V3 kAmbient = {0.08f, 0.24f, 0.08f};   // Iamb*ka as folded by glslang in shaders/shader.rgen.spv (0x3da3d70a, 0x3e75c28f)
+
+static Step bounce_step(const Scene& s, V3 o, V3 d, uint32_t i, bool hit, const Hit& h) {
+  const Uniforms& U = s.uni;
+  Step st{};
+  st.no = o; st.nd = d; st.objectIndex = -1;
+  if (!hit) { st.kind = STEP_SKY; st.sky = sample_sky(s, mk(d.x, d.y, -d.z)); return st; }
+  V3 P, N; int objectIndex;
+  closest_hit_attributes(s, h, P, N, objectIndex);
+  st.P = P; st.N = N; st.objectIndex = objectIndex;
+  uint32_t type = objectIndex == 0 ? U.centerObjectType : U.orbitingObjectType;
+  st.kind = STEP_CONTINUE;
+  if (type == 0) {
+    if (dot3(d, N) >= 0.0f) { st.kind = STEP_BACKFACE; return st; }
+    st.kind = STEP_SHADOW;
+    st.so = fma3(0.01f, N, P);
+    V3 toL = mk(U.lightPosition[0], U.lightPosition[1], U.lightPosition[2]) - P;
+    float dist = length3(toL);
+    V3 L = toL * (1.0f / dist);
+    st.sl = L; st.stmax = dist;
+    V3 Hh = normalize3(L + neg(d));
+    float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
+    float dl = std::max(0.0f, NdotL), sp = pow100(std::max(0.0f, NdotH));
+    float w = 1.0f; for (uint32_t k = 0; k < i; k++) w = w * 0.9f;  // pow(0.9, float(i)), i = SAMPLE index
+    float I = U.lightIntensity;
+    V3 diff = mk((I * 0.2f) * dl, (I * 1.0f) * dl, (I * 0.2f) * dl);
+    V3 spec = mk((I * 0.8f) * sp, (I * 0.8f) * sp, (I * 0.8f) * sp);
+    st.lit = fma3(w, diff + spec, kAmbient);   // tmpColor still holds Iamb*ka here: nothing else adds to it
+  } else if (type == 1) {
+    st.no = fma3(0.01f, N, P);
+    st.nd = reflect3(d, N);
+  } else if (type == 2) {
+    float ndoti = dot3(d, N);
+    bool outwards = ndoti > 0.0f;
+    if (outwards) { N = neg(N); ndoti = -ndoti; }
+    float ratio = outwards ? 1.52f : (1.0f / 1.52f);
+    float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
+    if (k < 0.0f) { st.nd = reflect3(d, N); st.no = fma3(0.01f, N, P); }
+    else {
+      float c = fmaf(ratio, ndoti, sqrtf(k));
+      V3 R = fma3(-c, N, d * ratio);
+      st.nd = normalize3(R);
+      st.no = fma3(-0.01f, N, P);
+    }
+  }
+  // any other type: the reference's loop re-traces the unchanged ray until the bounce budget ends
+  return st;
+}
+
 // One sample of one pixel: src/shader.rgen:70-181.
 static V3 shade_sample(const Scene& s, uint32_t px, uint32_t py, uint32_t W, uint32_t H, uint32_t i, bool use_bvh, RayCounts& rc, Counters* cnt) {
   const Uniforms& U = s.uni;
@@ -448,54 +518,22 @@ static V3 shade_sample(const Scene& s, uint32_t px, uint32_t py, uint32_t W, uin
   V3 o = mk(U.position[0], U.position[1], U.position[2]);
   V3 right = mk(U.right[0], U.right[1], U.right[2]), up = mk(U.up[0], U.up[1], U.up[2]), fwd = mk(U.forward[0], U.forward[1], U.forward[2]);
   V3 d = normalize3(fma3(2.5f, fwd, fma3(uy, up, right * ux)));
-  // Iamb*ka as folded by glslang in shaders/shader.rgen.spv (0x3da3d70a, 0x3e75c28f, 0x3da3d70a)
-  const V3 ambient = mk(0.08f, 0.24f, 0.08f);
-  V3 tmp = ambient;
+  V3 tmp = kAmbient;
   for (uint32_t j = 0; j <= U.maxBounceCount; j++) {
     Hit h;
     if (j == 0) rc.primary++; else rc.secondary++;
     bool hit = trace(s, o, d, 0.001f, 10000.0f, false, use_bvh, h, cnt);
-    if (!hit) { tmp = sample_sky(s, mk(d.x, d.y, -d.z)); break; }
-    V3 P, N; int objectIndex;
-    closest_hit_attributes(s, h, P, N, objectIndex);
-    uint32_t type = objectIndex == 0 ? U.centerObjectType : U.orbitingObjectType;
-    if (type == 0) {
-      if (dot3(d, N) >= 0.0f) break;
-      V3 so = fma3(0.01f, N, P);
-      V3 toL = mk(U.lightPosition[0], U.lightPosition[1], U.lightPosition[2]) - P;
-      float dist = length3(toL);
-      V3 L = toL * (1.0f / dist);
+    Step st = bounce_step(s, o, d, i, hit, h);
+    if (st.kind == STEP_SKY) { tmp = st.sky; break; }
+    if (st.kind == STEP_BACKFACE) break;
+    if (st.kind == STEP_SHADOW) {
       Hit sh;
       rc.shadow++;
-      bool occ = trace(s, so, L, 0.001f, dist, true, use_bvh, sh, cnt);
-      if (!occ) {
-        V3 Hh = normalize3(L + neg(d));
-        float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
-        float dl = std::max(0.0f, NdotL), sp = pow100(std::max(0.0f, NdotH));
-        float w = 1.0f; for (uint32_t k = 0; k < i; k++) w = w * 0.9f;  // pow(0.9, float(i)), i = SAMPLE index
-        float I = U.lightIntensity;
-        V3 diff = mk((I * 0.2f) * dl, (I * 1.0f) * dl, (I * 0.2f) * dl);
-        V3 spec = mk((I * 0.8f) * sp, (I * 0.8f) * sp, (I * 0.8f) * sp);
-        tmp = fma3(w, diff + spec, tmp);
-      }
+      bool occ = trace(s, st.so, st.sl, 0.001f, st.stmax, true, use_bvh, sh, cnt);
+      if (!occ) tmp = st.lit;
       break;
-    } else if (type == 1) {
-      o = fma3(0.01f, N, P);
-      d = reflect3(d, N);
-    } else if (type == 2) {
-      float ndoti = dot3(d, N);
-      bool outwards = ndoti > 0.0f;
-      if (outwards) { N = neg(N); ndoti = -ndoti; }
-      float ratio = outwards ? 1.52f : (1.0f / 1.52f);
-      float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
-      if (k < 0.0f) { d = reflect3(d, N); o = fma3(0.01f, N, P); }
-      else {
-        float c = fmaf(ratio, ndoti, sqrtf(k));
-        V3 R = fma3(-c, N, d * ratio);
-        d = normalize3(R);
-        o = fma3(-0.01f, N, P);
-      }
     }
+    o = st.no; d = st.nd;
   }
   return tmp;
 }
@@ -615,6 +653,44 @@ int orc_render(void* p, uint32_t W, uint32_t H, uint32_t y0, uint32_t y1, float*
     for (auto& t : th) t.join();
   }
   if (ray_counts) for (auto& r : rcs) { ray_counts[0] += r.primary; ray_counts[1] += r.secondary; ray_counts[2] += r.shadow; }
+  return 0;
+}
+
+// Replays n recorded bounces (rays o,d = 6 floats each; sample index; hit record, inst < 0 = miss) through bounce_step.
+// out: 28 floats per record = kind, P, N, objectIndex, so, sl, stmax, lit, no, nd, sky.
+int orc_bounce_step(void* p, uint64_t n, const float* od6, const uint32_t* sample_index, const Hit* hits, float* out28) {
+  Scene& s = *(Scene*)p;
+  if (!s.has_uni) return 1;
+  for (uint64_t k = 0; k < n; k++) {
+    const float* r = od6 + 6 * k;
+    Step st = bounce_step(s, mk(r[0], r[1], r[2]), mk(r[3], r[4], r[5]), sample_index[k], hits[k].inst >= 0, hits[k]);
+    float* o = out28 + 28 * k;
+    const V3 v[] = {st.P, st.N};
+    o[0] = (float)st.kind;
+    o[1] = v[0].x; o[2] = v[0].y; o[3] = v[0].z; o[4] = v[1].x; o[5] = v[1].y; o[6] = v[1].z; o[7] = (float)st.objectIndex;
+    o[8] = st.so.x; o[9] = st.so.y; o[10] = st.so.z; o[11] = st.sl.x; o[12] = st.sl.y; o[13] = st.sl.z; o[14] = st.stmax;
+    o[15] = st.lit.x; o[16] = st.lit.y; o[17] = st.lit.z;
+    o[18] = st.no.x; o[19] = st.no.y; o[20] = st.no.z; o[21] = st.nd.x; o[22] = st.nd.y; o[23] = st.nd.z;
+    o[24] = st.sky.x; o[25] = st.sky.y; o[26] = st.sky.z; o[27] = 0.f;
+  }
+  return 0;
+}
+
+// The pixels (x, y) of a W x H frame, one at a time (fixture replays): out = n RGBA values.
+int orc_render_pixels(void* p, uint32_t W, uint32_t H, uint64_t n, const uint32_t* xy, float* out, int use_bvh) {
+  Scene& s = *(Scene*)p;
+  if (!s.has_uni) return 1;
+  RayCounts rc;
+  const uint32_t spp = s.uni.samplesPerPixel;
+  for (uint64_t k = 0; k < n; k++) {
+    float c[4] = {0, 0, 0, 0};
+    for (uint32_t i = 0; i < spp; i++) {
+      V3 t = shade_sample(s, xy[2 * k], xy[2 * k + 1], W, H, i, use_bvh != 0, rc, nullptr);
+      c[0] += t.x; c[1] += t.y; c[2] += t.z; c[3] += 1.0f;
+    }
+    const float nn = (float)spp;
+    for (int q = 0; q < 4; q++) out[4 * k + q] = c[q] / nn;
+  }
   return 0;
 }
 

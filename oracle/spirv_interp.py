@@ -8,11 +8,11 @@ What the driver does for the reference is bound from outside: OpTraceRayKHR (acc
 OpImageSampleExplicitLod (the cube sampler) and OpImageWrite (the storage image) call back into the harness
 (tests/golden/make_spirv_fixtures.py binds them to the oracle's trace / sample_sky and a frame buffer).
 
-Arithmetic: OpFAdd/FSub/FMul/FDiv/FNegate and the conversions are IEEE binary32, one rounding per instruction, no
-contraction (the literal reading of the module: glslang emitted no NoContraction decoration, so a driver MAY fuse).
-OpDot, the matrix products and the GLSL.std.450 instructions (Sin, Pow, Normalize, Length, Reflect, Sqrt, Fract, FMin,
+Arithmetic: OpFAdd/FSub/FMul/FDiv/FNegate, OpDot and the conversions are IEEE binary32, one rounding per operation, left
+to right, no contraction (the literal reading of the module: glslang emitted no NoContraction decoration, so a driver MAY
+fuse).  The matrix products and the GLSL.std.450 instructions (Sin, Pow, Normalize, Length, Reflect, Sqrt, Fract, FMin,
 FMax) are evaluated in binary64 from their binary32 operands and rounded once — the "ideal" implementation the GLSL
-precision rules allow every driver to differ from by a few ulp.  Nothing here knows the oracle's canonical forms.
+precision rules allow every driver to differ from by a few ulp.  Nothing here calls the oracle's arithmetic.
 
 Only what the four modules need is implemented; an unknown opcode raises.
 """
@@ -270,6 +270,7 @@ class Invocation:
         self.m, self.env = module, env
         self.globals = {}
         self.steps = 0
+        self.watch = None      # {variable id: name}: env.on_store(name, value) is called after every OpStore to it
         shared = shared or {}
         for vid, (ptype, storage) in module.globals.items():
             if vid in shared:
@@ -303,7 +304,7 @@ class Invocation:
             op, w = insts[pc]
             pc += 1
             self.steps += 1
-            if op == OP["Label"] or op == OP["LoopMerge"] or op == OP["SelectionMerge"]:
+            if op == OP["Label"] or op == OP["LoopMerge"] or op == OP["SelectionMerge"] or op == OP["FunctionParameter"]:
                 continue
             if op == OP["Branch"]:
                 pc = fn["labels"][w[0]]
@@ -330,6 +331,8 @@ class Invocation:
                 if isinstance(v, list):
                     v = [list(c) if isinstance(c, list) else c for c in v]
                 V(w[0]).store(v)
+                if self.watch and w[0] in self.watch:      # stores to named variables the harness wants to see
+                    self.env.on_store(self.watch[w[0]], v)
             elif op == OP["AccessChain"]:
                 base = V(w[2])
                 vals[w[1]] = Pointer(base.cell, base.path + tuple(int(V(i)) for i in w[3:]))
@@ -388,7 +391,14 @@ class Invocation:
                 s = F32(V(w[3]))
                 vals[w[1]] = [F32(x) * s for x in V(w[2])]
             elif op == OP["Dot"]:
-                vals[w[1]] = F32(sum(float(a) * float(b) for a, b in zip(V(w[2]), V(w[3]))))
+                # literal binary32: products rounded, summed left to right, no contraction.  (The jitter hash of
+                # src/shader.rgen:57-59 is chaotic in the last bit of this dot product — its value feeds sin() at ~1e5 rad —
+                # so a fused or wider dot gives unrelated sub-pixel positions; SURVEY.md §8c trap 2.)
+                a, b = V(w[2]), V(w[3])
+                acc = F32(a[0]) * F32(b[0])
+                for x, y in zip(a[1:], b[1:]):
+                    acc = acc + F32(x) * F32(y)
+                vals[w[1]] = acc
             elif op == OP["MatrixTimesVector"]:
                 M, v = V(w[2]), V(w[3])                     # M = list of columns
                 rows = len(M[0])

@@ -107,3 +107,52 @@ def random_rays(n, seed, origin_radius=20.0, target_radius=4.0, tmin=0.001, tmax
     rays = np.zeros((n, 8), np.float32)
     rays[:, 0:3] = o; rays[:, 3] = tmin; rays[:, 4:7] = d; rays[:, 7] = tmax
     return rays
+
+
+# ---- fixtures produced by interpreting the reference's own SPIR-V shaders (tests/golden/make_spirv_fixtures.py) ---------------
+class SpirvFixtureScene:
+    def __init__(self, meta, bounces, pixels):
+        self.meta, self.bounces, self.pixels = meta, bounces, pixels
+        self.name, self.width, self.height = meta["name"], meta["width"], meta["height"]
+        self.paths = [os.path.join(ROOT, p) for p in meta["paths"]]
+        self.instances = np.frombuffer(bytes.fromhex("".join(meta["instances"])), INSTANCE_DTYPE).copy()
+        from vulkan_raytracing_amd.api import UNIFORMS_DTYPE
+        self.uniforms = np.frombuffer(bytes.fromhex(meta["uniforms"]), UNIFORMS_DTYPE).copy()
+        self.sky_dir = os.path.join(ROOT, meta["sky"]) if meta["sky"] else None
+        self._geom = None
+
+    @property
+    def geometry(self):
+        if self._geom is None:
+            self._geom = host.SceneGeometry(self.paths)
+        return self._geom
+
+    def apply(self, target):
+        """target: RtContext or the tests' oracle adapter (upload_geometry / set_instances / set_uniforms / set_skybox)"""
+        g = self.geometry
+        target.upload_geometry(g.verts, g.idx, g.ranges)
+        target.set_instances(self.instances)
+        target.set_uniforms(self.uniforms)
+        if self.sky_dir:
+            target.set_skybox(host.load_skybox(self.sky_dir))
+
+    def oracle_scene(self):
+        S = oracle.OracleScene()
+        g = self.geometry
+        S.set_geometry(g.verts, g.idx, g.ranges)
+        S.set_instances([self.instances[i].tobytes() for i in range(len(self.instances))])
+        S.set_uniforms(self.uniforms.tobytes())
+        if self.sky_dir:
+            S.set_skybox(host.load_skybox(self.sky_dir))
+        return S
+
+
+def load_spirv_fixtures():
+    import json
+    gold = os.path.join(ROOT, "tests", "golden")
+    meta = json.load(open(os.path.join(gold, "spirv_fixtures.json")))
+    data = np.load(os.path.join(gold, "spirv_fixtures.npz"), allow_pickle=False)
+    for kind in ("standin", "limbs"):      # the generated meshes the cfg3 / cfg5 scenes name (deterministic generators)
+        host.armadillo_path(RES, kind=kind)
+    b, p = data["bounces"], data["pixels"]
+    return [SpirvFixtureScene(m, b[b["scene"] == m["id"]], p[p["scene"] == m["id"]]) for m in meta["scenes"]]

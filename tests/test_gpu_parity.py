@@ -635,8 +635,11 @@ def test_cfg5_armadillo_x16_full_size(ctx, mesh):
     assert _logical_shards_equal_full(ctx, W, H, 8, a) == st.rays_total
     tgt = _OracleTarget()
     wl.apply(tgt)
-    # the band with the most bounce rays: rows where the teapot (mirror, RGB far from the green diffuse shading) sits
-    y0 = 8 * int(np.argmax([np.abs(a[y:y + 8, 700:1220, 0] - a[y:y + 8, 700:1220, 1]).sum() for y in range(0, H - 8, 8)]))
+    # the band through the middle of the mirror teapot (bounce rays): project its centre (0, 0.8, 0) with src/shader.rgen:74-79
+    u = wl.uniforms[0]
+    rel = np.array([0.0, 0.8, 0.0]) - u["position"][:3]
+    uy = 2.5 * float(rel @ u["up"][:3]) / float(rel @ u["forward"][:3])
+    y0 = 8 * int(((1.0 - uy) * 0.5 * H) // 8)
     part, rc = tgt.orc.render(W, H, y0=y0, y1=y0 + 8)
     d = np.abs(a[y0:y0 + 8] - part[y0:y0 + 8]).max(axis=2)
     assert (d <= TOL).mean() >= FRAC and (d == 0).mean() >= FRAC, (y0, float((d <= TOL).mean()), float((d == 0).mean()))
@@ -659,8 +662,8 @@ def test_cfg2_full_size_real_skybox(ctx):
     check_image(gpu, ref)
     assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
     assert st.rays_secondary > 0 and st.rays_shadow > 0
-    # most of the frame is sky: the real texture must actually have been sampled
-    assert len(np.unique(gpu[::8, ::8, :3].reshape(-1, 3), axis=0)) > 2000
+    # most of the frame is sky: the real texture (flat labelled faces, few colours) must actually have been sampled
+    assert len(np.unique(gpu[::8, ::8, :3].reshape(-1, 3), axis=0)) > 200
 
 
 @pytest.mark.parametrize("mesh", MESHES)
@@ -727,3 +730,31 @@ def test_tail_fault_falls_back_to_per_bounce_launches(ctx):
         assert np.array_equal(img, good) and st2.tail_faults == 1   # the context was already off k_tail: nothing to re-render
     finally:
         c2.close()
+
+
+def test_hip_frames_match_the_reference_spirv_pixels(ctx):
+    """The HIP path against tests/golden/spirv_fixtures.npz — pixels written by the reference's own shader.rgen.spv /
+    shader.rchit.spv / miss modules under an interpreter (tests/golden/make_spirv_fixtures.py), at the BASELINE sizes
+    (cfg1 256x256, cfg2 1280x720, cfg3 and cfg5 1920x1080 on both stand-in meshes).  Tolerance as in the CPU test of the
+    oracle: 2e-4 on >= 99.5 % of the pixels (the kernels trace their own rays, 1 ulp off the recorded ones).  The recorded
+    closest-hit rays go through rt_intersect as well: the hit records must be the recorded ones bit for bit."""
+    for sc in scenes.load_spirv_fixtures():
+        sc.apply(ctx)
+        img, _ = ctx.trace(sc.width, sc.height)
+        px = sc.pixels
+        got = img[px["py"], px["px"]]
+        d = np.abs(got - px["rgba"]).max(axis=1)
+        assert (d <= 2e-4).mean() >= 0.995, (sc.name, float((d <= 2e-4).mean()), float(d.max()))
+        b = sc.bounces
+        rays = np.zeros((len(b), 8), np.float32)
+        rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = b["o"], 0.001, b["d"], 10000.0
+        g, _ = ctx.intersect(rays)
+        assert np.array_equal(g["prim"], b["prim"]) and np.array_equal(g["inst"], b["inst"]), sc.name
+        hit = b["inst"] >= 0
+        for k in ("t", "u", "v"):
+            assert np.array_equal(g[k][hit].view(np.uint32), b[k][hit].view(np.uint32)), (sc.name, k)
+        sh = b["shadow"] == 1
+        srays = np.zeros((int(sh.sum()), 8), np.float32)
+        srays[:, 0:3], srays[:, 3], srays[:, 4:7], srays[:, 7] = b["so"][sh], 0.001, b["sl"][sh], b["stmax"][sh]
+        ga, _ = ctx.intersect(srays, any_hit=True)
+        assert np.array_equal(ga["inst"] >= 0, b["occluded"][sh] == 1), sc.name

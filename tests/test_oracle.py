@@ -263,3 +263,108 @@ def test_division_free_over_255_equals_ieee_division(tmp_path):
     subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-o", exe, src, "-lm", "-lpthread"], check=True)
     r = subprocess.run([exe, "61"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "mismatches 0" in r.stdout, r.stdout
+
+
+# ---- the reference's own compiled shaders as the judge of the restatement ---------------------------------------------------
+# tests/golden/spirv_fixtures.npz was produced by INTERPRETING /root/reference/shaders/*.spv (make_spirv_fixtures.py; the binaries
+# are read as data, the traversal / inverse transform / cube sampler are bound to the oracle).  Every record is one iteration
+# of the bounce loop as the reference's binaries executed it.  Bars: 1e-5 absolute (GLSL leaves the precision of normalize /
+# reflect / pow / dot open, so bit equality with any one implementation is not defined), 2e-5 on the lit colour because
+# pow(x, 100) by repeated squaring carries up to ~100 half-ulps of a term <= 0.8.
+SPV_TOL, SPV_TOL_LIT = 1e-5, 2e-5
+
+
+@pytest.fixture(scope="module")
+def spirv_fixture_scenes():
+    return scenes.load_spirv_fixtures()
+
+
+def test_spirv_fixture_covers_every_branch_of_the_shaders(spirv_fixture_scenes):
+    b = np.concatenate([sc.bounces for sc in spirv_fixture_scenes])
+    p = np.concatenate([sc.pixels for sc in spirv_fixture_scenes])
+    assert len(b) > 10000 and len(p) > 3000 and len(spirv_fixture_scenes) == 7
+    miss, hit = b["inst"] < 0, b["inst"] >= 0
+    assert miss.sum() > 1000 and hit.sum() > 5000
+    assert (b["shadow"] == 1).sum() > 2000 and ((b["shadow"] == 1) & (b["occluded"] == 0)).sum() > 500 and ((b["shadow"] == 1) & (b["occluded"] == 1)).sum() > 500
+    assert (b["last"] == 0).sum() > 2000                       # mirror / refract / TIR continuations
+    assert (hit & (b["shadow"] == 0) & (b["last"] == 1)).sum() > 10   # back-face break or bounce budget exhausted
+    assert b["bounce"].max() >= 5 and b["sample"].max() == 3
+    assert set(np.unique(b["object_index"])) == {-1, 0, 1}
+
+
+def test_oracle_replays_the_reference_spirv_records(spirv_fixture_scenes):
+    """rgen prologue (jitter hash, primary ray), rchit (closest_hit_attributes) and one bounce-loop iteration (bounce_step)
+    against what the reference's shader.rgen.spv / shader.rchit.spv / miss modules computed for the same inputs."""
+    from oracle.oracle import HIT_DTYPE
+    worst = {}
+
+    def track(key, err):
+        worst[key] = max(worst.get(key, 0.0), float(err))
+
+    for sc in spirv_fixture_scenes:
+        S, b, W, H = sc.oracle_scene(), sc.bounces, sc.width, sc.height
+        # -- src/shader.rgen:57-79: the primary ray of every sample
+        f = b[b["bounce"] == 0]
+        od = np.array([S.primary_ray(int(r["px"]), int(r["py"]), W, H, int(r["sample"])) for r in f])
+        assert np.array_equal(od[:, 0:3], f["o"])
+        track("primary ray", np.abs(od[:, 3:6] - f["d"]).max())
+        # -- the traversal the fixture was made with is this scene's (meshes regenerate identically, instances decode)
+        rays = np.zeros((len(b), 8), np.float32)
+        rays[:, 0:3], rays[:, 3], rays[:, 4:7], rays[:, 7] = b["o"], 0.001, b["d"], 10000.0
+        h = S.intersect(rays)
+        for k in ("prim", "inst"):
+            assert np.array_equal(h[k], b[k]), sc.name
+        assert np.array_equal(h["t"].view(np.uint32), b["t"].view(np.uint32))
+        # -- one loop iteration per record
+        hits = np.zeros(len(b), HIT_DTYPE)
+        for k in ("t", "u", "v", "prim", "inst"):
+            hits[k] = b[k]
+        st = S.bounce_step(np.concatenate([b["o"], b["d"]], axis=1), b["sample"].astype(np.uint32), hits)
+        kind = st[:, 0].astype(int)
+        hit, miss = b["inst"] >= 0, b["inst"] < 0
+        # rmiss: objectIndex = -1, sky colour, loop ends           (src/shader.rmiss:11, src/shader.rgen:90-94)
+        assert np.all(kind[miss] == 0) and np.all(b["object_index"][miss] == -1) and np.all(b["last"][miss] == 1)
+        if miss.any():
+            track("sky colour", np.abs(st[miss, 24:27] - b["color"][miss]).max())
+        # rchit payload                                             (src/shader.rchit:50-96)
+        assert np.array_equal(st[hit, 7].astype(int), b["object_index"][hit])
+        track("payload.hitPosition", np.abs(st[hit, 1:4] - b["P"][hit]).max())
+        track("payload.hitNormal", np.abs(st[hit, 4:7] - b["N"][hit]).max())
+        # diffuse: back-face break, or shadow ray + Blinn-Phong      (src/shader.rgen:97-131)
+        sh = b["shadow"] == 1
+        assert np.array_equal(kind == 2, sh), sc.name
+        if sh.any():
+            track("shadow ray origin", np.abs(st[sh, 8:11] - b["so"][sh]).max())
+            track("shadow ray direction", np.abs(st[sh, 11:14] - b["sl"][sh]).max())
+            track("shadow ray tmax", np.abs(st[sh, 14] - b["stmax"][sh]).max())
+            lit = sh & (b["occluded"] == 0)
+            track("lit colour", np.abs(st[lit, 15:18] - b["color"][lit]).max())
+            dark = sh & (b["occluded"] == 1)
+            assert np.all(b["color"][dark] == np.array([0.08, 0.24, 0.08], np.float32))   # tmpColor keeps Iamb*ka
+        back = kind == 1
+        assert np.all(b["last"][back] == 1) and np.all(b["color"][back] == np.array([0.08, 0.24, 0.08], np.float32))
+        # mirror / refract / TIR: the next ray                       (src/shader.rgen:132-165)
+        cont = kind == 3
+        go_on = cont & (b["last"] == 0)
+        assert np.array_equal(b["last"] == 0, go_on)                # the recorded loop continued exactly where bounce_step says so
+        if go_on.any():
+            track("next rayOrigin", np.abs(st[go_on, 18:21] - b["no"][go_on]).max())
+            track("next rayDirection", np.abs(st[go_on, 21:24] - b["nd"][go_on]).max())
+        ended = cont & (b["last"] == 1)                             # bounce budget exhausted: j == maxBounceCount
+        assert np.all(b["bounce"][ended] == int(sc.uniforms[0]["max_bounce_count"]))
+    for k, v in worst.items():
+        assert v <= (SPV_TOL_LIT if k == "lit colour" else SPV_TOL), (k, v, worst)
+    assert worst["sky colour"] == 0.0 and worst["primary ray"] <= 2.5e-7
+
+
+def test_oracle_pixels_match_the_reference_spirv_pixels(spirv_fixture_scenes):
+    """Whole pixels (sample loop, accumulation, division; src/shader.rgen:64-70,180-185) against the values the interpreted
+    shader.rgen.spv wrote with OpImageWrite.  The oracle traces its OWN rays here, which differ from the recorded ones in the
+    last bit (normalize, fma): a ray may then fall on the other side of a triangle edge, and a 1-ulp change of a sky direction
+    moves the bilinear weights of a 2048^2 JPEG face by 1e-4 texel — hence 2e-4 and an outlier budget of 0.5 %."""
+    for sc in spirv_fixture_scenes:
+        S, px = sc.oracle_scene(), sc.pixels
+        img = S.render_pixels(sc.width, sc.height, np.stack([px["px"], px["py"]], axis=1))
+        d = np.abs(img - px["rgba"]).max(axis=1)
+        assert (d <= 2e-4).mean() >= 0.995, (sc.name, float((d <= 2e-4).mean()), float(d.max()))
+        assert np.all(img[:, 3] == 1.0) and np.all(px["rgba"][:, 3] == 1.0)
