@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
-"""bench.py — Mrays/s (primary + secondary + shadow) of the MI355X ray-tracing stage on BASELINE
-config 3: teapot.obj (mirror) + armadillo (diffuse; STAND-IN mesh unless resources/armadillo.obj is
-supplied) + skybox_texture_sea, 1920x1080, depth 4 (maxBounceCount 3) + shadow rays, spp 4.
+"""bench.py — Mrays/s (primary + secondary + shadow) of the MI355X ray-tracing stage on BASELINE config 3:
+teapot.obj (mirror) + armadillo (diffuse; a STAND-IN mesh unless resources/armadillo.obj is supplied) +
+skybox_texture_sea, 1920x1080, depth 4 (maxBounceCount 3) + shadow rays, spp 4.
 
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-One process per GPU, --frames-in-flight independent frames in flight per GPU (the reference's swapchain keeps
-minImageCount + 1 frames in flight, src/main.cpp:1203, 2967), each on its own HIP stream with its own hardware queue:
-4 frames / the 4 default queues on one GPU, 8 frames / GPU_MAX_HW_QUEUES=8 when the frame is sharded.  A step = one frame of the hot path: raygen -> [closest-hit traversal -> shade]
-x 4 bounces -> any-hit shadow traversal -> resolve, on this rank's interleaved 8-row bands, followed
-(N > 1) by ONE RCCL gather of the compact shards to rank 0 and the row permutation that reassembles
-the frame.  The frame is fixed, so scaling is STRONG.  Inputs (scene, BVH, cube map) are resident in
-HBM before the timed region.  Rank 0 prints one JSON line.
+One process per GPU.  Per GPU ONE scene (geometry, BLAS, cube map) resident in HBM and --frames-in-flight frame slots on
+it (rt_create_frame_slot: instances/TLAS, uniforms, ray queues, counters, stream per slot) — the reference's swapchain keeps
+minImageCount + 1 frames in flight on shared buffers and acceleration structures (src/main.cpp:1203, 2597, 2967).  A step =
+one frame of the hot path (raygen -> [closest-hit traversal -> shade] x 4 bounces -> any-hit shadow traversal -> resolve)
+on this rank's interleaved 8-row bands, followed (N > 1) by ONE RCCL gather of the compact shards to rank 0 and the row
+permutation that reassembles the frame.  The frame is fixed, so scaling is STRONG.  Rank 0 prints one JSON line.
+
+Besides `value` (the contract: t = 0 frames, timed region of K steps) the line carries
+  ms_per_frame_single   one frame at a time (SURVEY.md §8d "wall time of the trace pipeline for one frame")
+  animated_ms_per_step  the reference's real loop: per step animate -> rt_set_instances(update=1) (TLAS refit) ->
+                        rt_set_uniforms -> frame (src/main.cpp:2836-2861, 2901-2903), frames in flight preserved
+  other_mesh            the same workload on the other stand-in mesh (N = 1 only)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -36,54 +42,169 @@ import torch.distributed as dist  # noqa: E402
 
 from vulkan_raytracing_amd import RtContext, host, tiling, workloads  # noqa: E402
 
-WIDTH, HEIGHT, MAX_BOUNCE, SPP = 1920, 1080, 3, 4   # BASELINE config 3 (the headline); --workload cfg4 / cfg5 change them
-WORKLOAD = "cfg3"
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy peak)
 RAY_BYTES, HIT_BYTES = 32, 20
+ANIM_DT = 1.0 / 60.0    # fixed time step of the animated leg (the reference uses the wall clock, src/main.cpp:2798-2800)
 
 
-_WL = {}
+def kernels_sha16():
+    """identifies the kernel sources a profile was taken with (profiles/*.json carry the same field)"""
+    h = hashlib.sha256()
+    for f in ("kernels.hip", "rt_api.cpp", "bvh_gpu.hip", "bvh_build.cpp", "rt_device.h"):
+        h.update(open(os.path.join(ROOT, "vulkan_raytracing_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
-def workload(res, mesh):
-    # host-side ingest (OBJ parse, JPEG decode) happens once per process; every context gets its own upload + BLAS/TLAS
-    key = (WORKLOAD, mesh)
-    if key not in _WL:
-        _WL[key] = workloads.make(WORKLOAD, res, mesh=mesh)
-    return _WL[key]
+def visible_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:   # cgroup v2 CPU quota, if the box sets one
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        pass
+    return n, quota
 
 
-def cpu_baseline(wl, budget_s=12.0):
-    """The oracle (oracle/rt_oracle.cpp, kind "port") on this box's host cores: whole 1920x1080 frames of
-    the same workload, repeated until about `budget_s` seconds of CPU work.  Checker code: used here ONLY
-    as the reported CPU baseline, never by the product path.  Threads = the box's CPU share for one GPU
-    (16) unless RT_CPU_THREADS says otherwise."""
+def cpu_baseline(wl, budget_s=14.0):
+    """The oracle (oracle/rt_oracle.cpp, kind "port") built -O3 -march=native ON THIS BOX and timed on its host cores:
+    whole frames of the same workload on every visible core, plus a 1-thread figure on a band of rows.  Checker code:
+    used here ONLY as the reported CPU baseline, never by the product path."""
     from oracle import oracle as orc
-    S = orc.OracleScene()
+    S = orc.OracleScene(native=True)
     geom, inst = wl.geometry, wl.instances
     S.set_geometry(geom.verts, geom.idx, geom.ranges)
     S.set_instances([inst[i].tobytes() for i in range(len(inst))])
     S.set_uniforms(wl.uniforms.tobytes())
     S.set_skybox(wl.sky)
-    avail = os.cpu_count() or 1
-    try:
-        avail = len(os.sched_getaffinity(0))
-    except AttributeError:
-        pass
-    cores = int(os.environ.get("RT_CPU_THREADS", min(avail, 16)))
+    W, H = wl.width, wl.height
+    visible, quota = visible_cores()
+    cores = int(os.environ.get("RT_CPU_THREADS", visible))
     t0 = time.time()
-    _, rc = S.render(WIDTH, HEIGHT, threads=cores)
+    _, rc = S.render(W, H, threads=cores)
     one = max(time.time() - t0, 1e-3)
-    reps = int(max(1, min(200, round(budget_s / one))))
+    reps = int(max(1, min(400, round(budget_s * 0.6 / one))))
     rays = 0
     t0 = time.time()
     for _ in range(reps):
-        _, rc = S.render(WIDTH, HEIGHT, threads=cores)
+        _, rc = S.render(W, H, threads=cores)
         rays += int(rc.sum())
     dt = time.time() - t0
+    # one thread: the 64 rows through the middle of the frame (where the meshes are), repeated for ~40 % of the budget
+    y0 = (H // 2 - 32) & ~7
+    t0 = time.time()
+    _, rc1 = S.render(W, H, y0=y0, y1=y0 + 64, threads=1)
+    one1 = max(time.time() - t0, 1e-3)
+    reps1 = int(max(1, min(200, round(budget_s * 0.4 / one1))))
+    rays1 = 0
+    t0 = time.time()
+    for _ in range(reps1):
+        _, rc1 = S.render(W, H, y0=y0, y1=y0 + 64, threads=1)
+        rays1 += int(rc1.sum())
+    dt1 = time.time() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": cores, "kind": "port",
-            "sample": "%d full %dx%d frames of the same workload (%d rays, %.1f s), oracle/rt_oracle.cpp with its own SAH BVH, %d threads of %d visible"
-                      % (reps, WIDTH, HEIGHT, rays, dt, cores, avail)}
+            "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
+                           "sample": "%d x rows %d..%d of the frame (%d rays, %.1f s)" % (reps1, y0, y0 + 63, rays1, dt1)},
+            "sample": "%d full %dx%d frames of the same workload (%d rays, %.1f s): oracle/rt_oracle.cpp built g++ -O3 -march=native -ffp-contract=off on this box, "
+                      "its own SAH BVH, %d threads = every core visible to the process (%s)"
+                      % (reps, W, H, rays, dt, cores, "cgroup CPU quota %.1f" % quota if quota else "no cgroup CPU quota")}
+
+
+class Rig:
+    """One scene on this rank's GPU + P frame slots, their output buffers and streams; step() enqueues one frame."""
+
+    def __init__(self, wl, P, dev, local_rank, rank, n, args, collective):
+        self.wl, self.P, self.dev, self.rank, self.n, self.args, self.collective = wl, P, dev, rank, n, args, collective
+        W, H = wl.width, wl.height
+        root = RtContext(local_rank)
+        if args.variant is not None:
+            root.set_param("trace_variant", args.variant)
+        wl.apply(root)                       # geometry + BLAS + cube map once per GPU; instances / uniforms of slot 0
+        self.ctxs = [root] + [root.frame_slot() for _ in range(P - 1)]
+        for c in self.ctxs[1:]:
+            c.set_instances(wl.instances)
+            c.set_uniforms(wl.uniforms)
+        for c in self.ctxs:
+            for kv in args.param:
+                k, v = kv.split("=")
+                c.set_param(k, int(v))
+            if args.blocks_per_cu is not None:
+                c.set_param("trace_blocks_per_cu", args.blocks_per_cu)
+        band = self.band = tiling.BAND_ROWS
+        rows_max = self.rows_max = tiling.max_shard_rows(H, band, n)
+        self.shards = [torch.zeros((rows_max, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
+        # the gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183)
+        root_rank = rank == 0 and collective
+        self.gathered = [torch.zeros((n, rows_max, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
+        self.full = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
+        self.perm = None
+        if root_rank:
+            src = np.zeros(H, np.int64)
+            for s in range(n):
+                m = tiling.shard_row_map(H, band, s, n)
+                src[m] = s * rows_max + np.arange(len(m))
+            self.perm = torch.as_tensor(src, device=dev)
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
+        self.frames = [None] * P
+        self.counter = 0
+        # animated leg: fixed-step clock, the reference's transforms (src/main.cpp:2836-2844)
+        self.time_param = np.float32(0.0)
+
+    def step(self, animate=False):
+        a, n, rank, W, H = self.args, self.n, self.rank, self.wl.width, self.wl.height
+        j = self.counter % self.P
+        self.counter += 1
+        c = self.ctxs[j]
+        if animate:
+            # src/main.cpp:2798-2800, 2836-2861, 2901-2903: advance the clock, animate both transforms, createTLAS(update = true),
+            # copy the uniform block — on the slot about to be submitted (waits for THAT slot's previous frame only)
+            self.time_param = np.float32(self.time_param + np.float32(ANIM_DT) * np.float32(0.1))
+            c.set_instances(self.wl.animate(self.time_param), update=True)
+            c.set_uniforms(self.wl.uniforms)
+        with torch.cuda.stream(self.streams[j]):
+            c.trace_shard(W, H, self.band, rank, n, self.shards[j].data_ptr(), self.shards[j].numel() * 4, self.streams[j].cuda_stream)
+            if n > 1 and a.rehearse_on_one_gpu:
+                self.streams[j].synchronize()
+                host_shard = self.shards[j].cpu()
+                parts = [torch.zeros_like(host_shard) for _ in range(n)] if rank == 0 else None
+                dist.gather(host_shard, parts, dst=0)
+                if rank == 0:
+                    self.frames[j] = torch.cat(parts).index_select(0, self.perm.cpu()).to(self.dev)
+            elif self.collective:
+                rgb = self.shards[j][..., :3].contiguous()
+                dist.gather(rgb, list(self.gathered[j].unbind(0)) if rank == 0 else None, dst=0)
+                if rank == 0:
+                    torch.index_select(self.gathered[j].view(n * self.rows_max, W, 3), 0, self.perm, out=self.full[j])
+                    self.frames[j] = self.full[j]
+            else:
+                self.frames[j] = self.shards[j]
+
+    def sync(self):
+        for s_ in self.streams:
+            s_.synchronize()
+        torch.cuda.synchronize(self.dev)
+        if self.collective:
+            dist.barrier()
+            torch.cuda.synchronize(self.dev)
+
+    def timed(self, steps, warmup, animate=False):
+        for _ in range(warmup):
+            self.step(animate)
+        self.sync()
+        self.ctxs[0].stats()       # drop the warm-up frames' event times
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(animate)
+        self.sync()
+        return time.perf_counter() - t0
+
+    def close(self):
+        for c in reversed(self.ctxs):
+            c.close()
 
 
 def main():
@@ -92,10 +213,11 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="independent frames in flight per GPU, each on its own stream and buffers; the reference keeps "
-                         "swapchainImageCount = minImageCount + 1 frames in flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: "
-                         "4 on one GPU, 8 when the frame is split over several — one per HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
+                    help="frame slots per GPU, each with its own stream; the reference keeps swapchainImageCount = minImageCount + 1 frames in "
+                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 on one GPU, 8 when the frame is split over several — one per "
+                         "HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the animated leg, the single-frame latency and the second mesh (profiling runs)")
     ap.add_argument("--param", action="append", default=[], help="rt_set_param NAME=VALUE on every context (experiments), repeatable")
     ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
     ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray; 2 = 4-ary records, one lane per ray")
@@ -103,18 +225,15 @@ def main():
     ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
                     help="cfg3 (default, the headline): 1920x1080 depth 4; cfg4: 3840x2160 depth 6; cfg5: 16 instances of the armadillo BLAS, 1920x1080 depth 4")
     ap.add_argument("--mesh", default="standin", choices=["limbs", "standin"],
-                    help="which stand-in replaces the missing resources/armadillo.obj: limbs = the non-star-shaped figure (default, "
-                         "the harder and more armadillo-like one), standin = the geodesic blob of round 1; ignored when the real file is supplied")
+                    help="which stand-in replaces the missing resources/armadillo.obj: standin = the geodesic blob (default: the mesh of round 1, and by "
+                         "node visits per ray the harder of the two), limbs = the non-star-shaped figure; ignored when the real file is supplied")
+    ap.add_argument("--animate", action="store_true", help="make the animated loop THE timed region (value then counts animated frames); without it the animated loop is a second field")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
                          "reassembly where only one GPU exists (its throughput is meaningless)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with one rank: still create the RCCL process group and run the per-frame gather (to itself) — a smoke test of the N > 1 code path")
     args = ap.parse_args()
-    global WIDTH, HEIGHT, MAX_BOUNCE, WORKLOAD
-    WORKLOAD = args.workload
-    if WORKLOAD == "cfg4":
-        WIDTH, HEIGHT, MAX_BOUNCE = 3840, 2160, 5
 
     # stdout carries exactly one JSON line: library banners (RCCL prints its version to fd 1) go to stderr
     sys.stdout.flush()
@@ -153,87 +272,18 @@ def main():
         host.armadillo_path(res, kind=args.mesh)  # generate the stand-in once before the other ranks look for it
     if collective:
         dist.barrier()
-    wl = workload(res, args.mesh)
-    # one context (scene replica, queues, counters) per frame in flight — the analogue of the reference's
-    # per-swapchain-image command buffer, fence and semaphores (src/main.cpp:2597, 2740-2749)
-    ctxs = []
+    wl = workloads.make(args.workload, res, mesh=args.mesh)
+    W, H = wl.width, wl.height
+    rig = Rig(wl, P, dev, local_rank, rank, n, args, collective)
+    ctx = rig.ctxs[0]
+
+    ctx.set_timing(True)   # HIP events around every kernel of slot 0's frames (every P-th frame), on their own stream
+    # set-up, not a step: one frame per slot so that every slot has its ray queues allocated before the warm-up/timed steps
     for _ in range(P):
-        c = RtContext(local_rank)
-        wl.apply(c)
-        if args.variant is not None:
-            c.set_param("trace_variant", args.variant)
-        for kv in args.param:
-            k, v = kv.split("=")
-            c.set_param(k, int(v))
-        if args.blocks_per_cu is not None:
-            c.set_param("trace_blocks_per_cu", args.blocks_per_cu)
-        ctxs.append(c)
-    ctx = ctxs[0]
-
-    band = tiling.BAND_ROWS
-    rows_max = tiling.max_shard_rows(HEIGHT, band, n)
-    shards = [torch.zeros((rows_max, WIDTH, 4), dtype=torch.float32, device=dev) for _ in range(P)]
-    # the gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183),
-    # so 25 % of the xGMI traffic into rank 0 would be constants
-    gathered = [torch.zeros((n, rows_max, WIDTH, 3), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
-    # the assembled frame on rank 0 stays RGB (alpha is the constant 1.0): the row permutation writes it in one kernel
-    full = [torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev) if (rank == 0 and collective) else None for _ in range(P)]
-    perm = None
-    if rank == 0 and collective:
-        src = np.zeros(HEIGHT, np.int64)
-        for s in range(n):
-            m = tiling.shard_row_map(HEIGHT, band, s, n)
-            src[m] = s * rows_max + np.arange(len(m))
-        perm = torch.as_tensor(src, device=dev)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(P)]
-    frames = [None] * P
-    counter = [0]
-
-    def step():
-        j = counter[0] % P
-        counter[0] += 1
-        with torch.cuda.stream(streams[j]):
-            ctxs[j].trace_shard(WIDTH, HEIGHT, band, rank, n, shards[j].data_ptr(), shards[j].numel() * 4, streams[j].cuda_stream)
-            if n > 1 and args.rehearse_on_one_gpu:
-                streams[j].synchronize()
-                host_shard = shards[j].cpu()
-                parts = [torch.zeros_like(host_shard) for _ in range(n)] if rank == 0 else None
-                dist.gather(host_shard, parts, dst=0)
-                if rank == 0:
-                    frames[j] = torch.cat(parts).index_select(0, perm.cpu()).to(dev)
-            elif collective:
-                rgb = shards[j][..., :3].contiguous()
-                dist.gather(rgb, list(gathered[j].unbind(0)) if rank == 0 else None, dst=0)
-                if rank == 0:
-                    torch.index_select(gathered[j].view(n * rows_max, WIDTH, 3), 0, perm, out=full[j])
-                    frames[j] = full[j]
-            else:
-                frames[j] = shards[j]
-
-    def sync():
-        for s_ in streams:
-            s_.synchronize()
-        torch.cuda.synchronize(dev)
-        if collective:
-            dist.barrier()
-            torch.cuda.synchronize(dev)
-
-    ctx.set_timing(True)   # HIP events around every kernel of context 0's frames (every P-th frame), on their own stream
-    # set-up, not a step: one frame per context so that every context has its ray queues allocated before the
-    # warm-up/timed steps start (a context allocates them on its first frame)
-    for _ in range(P):
-        step()
-    sync()
-    for _ in range(args.warmup):
-        step()
-    sync()
-    ctx.stats()             # drop the warm-up frames' event times
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    sync()
-    dt = time.perf_counter() - t0
-    st = ctx.stats()        # counters of context 0's last frame + MEAN event times over all its timed frames (every P-th step)
+        rig.step()
+    rig.sync()
+    dt = rig.timed(args.steps, args.warmup, animate=args.animate)
+    st = ctx.stats()        # counters of slot 0's last frame + MEAN event times over all its timed frames (every P-th step)
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_secondary, st.rays_shadow], dtype=torch.float64, device=dev)
     if collective:
@@ -243,14 +293,30 @@ def main():
     rays_frame = [int(x) for x in rays.tolist()]
     total_rays = sum(rays_frame)
 
+    # ---- the animated loop as a second timed region (every rank takes part: it contains the gather) ----------------------
+    anim_ms = None
+    if not args.no_extras and not args.animate:
+        ctx.set_timing(False)
+        dta = rig.timed(args.steps, max(P, args.warmup), animate=True)
+        ta = torch.tensor([dta], dtype=torch.float64, device=dev)
+        if collective:
+            dist.all_reduce(ta, op=dist.ReduceOp.MAX)
+        anim_ms = float(ta.item()) / args.steps * 1e3
+        # back to the t = 0 scene for the measurements below
+        for c in rig.ctxs:
+            c.set_instances(wl.instances)
+        rig.sync()
+        ctx.set_timing(True)
+
     result = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
         value = total_rays * args.steps / dt / 1e6
+        mb = int(wl.uniforms[0]["max_bounce_count"])
         # the headline workload reports BASELINE.json's own metric string; "secondary" there = every ray after the primary one,
         # i.e. bounce rays + shadow rays (config.rays_per_frame lists the classes)
-        metric = "Mrays/sec (primary+secondary+shadow) at %dx%d depth %d" % (WIDTH, HEIGHT, MAX_BOUNCE + 1)
-        if WORKLOAD == "cfg3":
+        metric = "Mrays/sec (primary+secondary+shadow) at %dx%d depth %d" % (W, H, mb + 1)
+        if args.workload == "cfg3":
             try:
                 metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
             except Exception:
@@ -258,23 +324,35 @@ def main():
         result = {"metric": metric, "value": value, "unit": "Mrays/s",
                   "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": wl.describe(), "mesh": wl.mesh_label,
+                  "animated_ms_per_step": anim_ms,
+                  "config": {"workload": wl.describe() + (" [animated loop timed]" if args.animate else ""), "mesh": wl.mesh_label,
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
                              "ray_classes": "value counts every traceRayEXT-equivalent: primary + secondary (bounce) + shadow rays; 'secondary' in the metric string means both",
-                             "parallelism": "interleaved %d-row bands over %d GPU(s), scene replicated, one RCCL gather per frame, %d frames in flight per GPU" % (band, n, P),
-                             "frames_in_flight": P, "device": ctx.device_info}}
+                             "parallelism": "interleaved %d-row bands over %d GPU(s), one scene per GPU, one RCCL gather per frame, %d frame slots in flight per GPU" % (rig.band, n, P),
+                             "frames_in_flight": P, "device": ctx.device_info,
+                             "animated_loop": "per step: animate (fixed dt 1/60 s) -> rt_set_instances(update=1) = TLAS refit -> rt_set_uniforms -> frame; src/main.cpp:2836-2861, 2901-2903"}}
     # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's shard -----------------
     if rank == 0:
-        # (1) isolated frames: the same shard, one frame at a time on context 0, HIP events around every kernel
+        # (1) isolated frames: the same shard, one frame at a time on slot 0, HIP events around every kernel
         iso = []
         for _ in range(5):
-            ctx.trace_shard(WIDTH, HEIGHT, band, rank, n, shards[0].data_ptr(), shards[0].numel() * 4, streams[0].cuda_stream)
+            ctx.trace_shard(W, H, rig.band, rank, n, rig.shards[0].data_ptr(), rig.shards[0].numel() * 4, rig.streams[0].cuda_stream)
             iso.append(ctx.stats())
         iso_ms = sorted(x.ms_trace_closest for x in iso)[len(iso) // 2]
         ctx.set_timing(False)
+        # one frame at a time, wall clock (enqueue + wait), rank 0's shard
+        if not args.no_extras:
+            for _ in range(3):
+                ctx.trace_shard(W, H, rig.band, rank, n, rig.shards[0].data_ptr(), rig.shards[0].numel() * 4, rig.streams[0].cuda_stream)
+                ctx.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                ctx.trace_shard(W, H, rig.band, rank, n, rig.shards[0].data_ptr(), rig.shards[0].numel() * 4, rig.streams[0].cuda_stream)
+                ctx.synchronize()
+            result["ms_per_frame_single"] = (time.perf_counter() - t0) / 20 * 1e3
         # (2) mean node visits / triangle tests per ray from the instrumented build of the same kernel over the
         # full frame (exact for n == 1; for n > 1 rank 0's bands are an interleaved sample of it)
-        _, cst = ctx.trace(WIDTH, HEIGHT, counting=True)
+        _, cst = ctx.trace(W, H, counting=True)
         mean_nodes = cst.node_visits / max(1, cst.closest_rays)
         mean_tris = cst.tri_tests / max(1, cst.closest_rays)
         # rays that entered the k_trace<closest> launches: survivors of the TLAS-root test, plus the secondary rays unless
@@ -285,34 +363,70 @@ def main():
         live_s = st.ms_trace_closest * 1e-3
         achieved = alg_bytes / live_s / 1e9 if live_s > 0 else 0.0
         achieved_iso = alg_bytes / (iso_ms * 1e-3) / 1e9 if iso_ms > 0 else 0.0
-        result["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                              "traffic": None,
-                              "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore; bounces >= 1 run inside k_tail when few paths survive",
-                              "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
-                              "algorithmic_bytes_per_launch": alg_bytes / launches,
-                              "timing": "HIP events on the kernel's own stream, live in the timed region: mean over context 0's %d timed frames (every %d-th step); with %d frames "
-                                        "in flight the kernel shares the GPU with the kernels of the other frames, so a launch lasts longer than when it runs alone" % (st.timed_frames, P, P),
-                              "isolated": {"achieved": achieved_iso, "frac": achieved_iso / HBM_PEAK_GBS, "avg_launch_ms": iso_ms / launches,
-                                           "timing": "median of 5 frames run one at a time right after the timed region (same process, same buffers)"},
-                              "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,
-                              "node_bytes": cst.bvh_node_bytes, "tri_bytes": cst.bvh_tri_bytes,
-                              "frame_kernel_ms": {"raygen": st.ms_raygen, "trace_closest": st.ms_trace_closest, "shade": st.ms_shade,
-                                                  "trace_shadow": st.ms_trace_shadow, "resolve": st.ms_resolve, "tail": st.ms_tail, "frame": st.ms_frame},
-                              "note": "scene (BVH+triangles ~25 MB) and cube map (96 MiB) fit the 256 MiB Infinity Cache: HBM traffic << algorithmic bytes"}
-        traffic_file = os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")
-        if os.path.exists(traffic_file):
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "definition": "achieved/frac = ALGORITHMIC bytes (SURVEY.md §8d: per ray 32 B ray + 20 B hit + visited nodes x node bytes + tested triangles x packet bytes) / launch "
+                              "time / 8 TB/s.  It is a work rate priced as if every visited node came from HBM; the scene is cache resident, so it is NOT HBM utilisation: see "
+                              "hbm_measured and limiter",
+                "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore; bounces >= 1 run inside k_tail when few paths survive",
+                "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
+                "algorithmic_bytes_per_launch": alg_bytes / launches,
+                "timing": "HIP events on the kernel's own stream, live in the timed region: mean over slot 0's %d timed frames (every %d-th step); with %d frames "
+                          "in flight the kernel shares the GPU with the kernels of the other frames, so a launch lasts longer than when it runs alone" % (st.timed_frames, P, P),
+                "isolated": {"achieved": achieved_iso, "frac": achieved_iso / HBM_PEAK_GBS, "avg_launch_ms": iso_ms / launches,
+                             "timing": "median of 5 frames run one at a time right after the timed region (same process, same buffers)"},
+                "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,
+                "node_bytes": cst.bvh_node_bytes, "tri_bytes": cst.bvh_tri_bytes,
+                "frame_kernel_ms": {"raygen": st.ms_raygen, "trace_closest": st.ms_trace_closest, "shade": st.ms_shade,
+                                    "trace_shadow": st.ms_trace_shadow, "resolve": st.ms_resolve, "tail": st.ms_tail, "frame": st.ms_frame},
+                "rocprof": None, "hbm_measured": None}
+        # rocprofv3 figures are attached ONLY when the committed profile was taken on this very configuration and kernel source
+        tag = {"workload": args.workload, "mesh": args.mesh, "variant": args.variant or 0, "n_gpus": n, "frames_in_flight": P, "kernels_sha16": kernels_sha16()}
+        prof_file = os.path.join(ROOT, "profiles", "latest_profile.json")
+        if os.path.exists(prof_file):
             try:
-                result["roofline"]["traffic"] = json.load(open(traffic_file)).get("hbm_bytes_per_launch")
-            except Exception:
-                pass
-        last = (counter[0] - 1) % P
-        if args.save_image and frames[last] is not None:
-            img = frames[last][:HEIGHT].cpu().numpy()
+                prof = json.load(open(prof_file))
+                if all(prof.get("tag", {}).get(k) == v for k, v in tag.items()):
+                    k_ms = prof["k_trace_closest_avg_ms"]
+                    roof["rocprof"] = {"avg_launch_ms": k_ms, "achieved": alg_bytes / launches / (k_ms * 1e-3) / 1e9,
+                                       "frac": alg_bytes / launches / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "profile": prof.get("source")}
+                    if prof.get("hbm_bytes_per_launch"):
+                        roof["traffic"] = prof["hbm_bytes_per_launch"]
+                        roof["hbm_measured"] = {"bytes_per_launch": prof["hbm_bytes_per_launch"], "GB/s": prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9,
+                                                "frac_of_peak": prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "profile": prof.get("traffic_source")}
+                    if prof.get("limiter"):
+                        roof["limiter"] = prof["limiter"]
+                else:
+                    roof["profile_note"] = "profiles/latest_profile.json was taken on another configuration or kernel source (%s): rocprof / traffic figures withheld" % json.dumps(prof.get("tag"))
+            except Exception as e:   # noqa: BLE001
+                roof["profile_note"] = "profiles/latest_profile.json unreadable: %r" % (e,)
+        result["roofline"] = roof
+        last = (rig.counter - 1) % P
+        if args.save_image and rig.frames[last] is not None:
+            img = rig.frames[last][:H].cpu().numpy()
             if img.shape[-1] == 3:   # assembled multi-rank frame: RGB + the constant alpha
                 img = np.concatenate([img, np.ones(img.shape[:2] + (1,), np.float32)], axis=-1)
             with open(args.save_image, "wb") as fh:
-                fh.write(b"PF4\n%d %d\n-1.0\n" % (WIDTH, HEIGHT))
+                fh.write(b"PF4\n%d %d\n-1.0\n" % (W, H))
                 fh.write(img[::-1].astype("<f4").tobytes())
+    rig.close()
+    if rank == 0:
+        # ---- the same workload on the other stand-in mesh (one GPU only) -------------------------------------------------
+        if n == 1 and not args.no_extras and not collective and args.workload in ("cfg3", "cfg5") and not os.path.exists(os.path.join(res, "armadillo.obj")):
+            other = "limbs" if args.mesh == "standin" else "standin"
+            wl2 = workloads.make(args.workload, res, mesh=other)
+            rig2 = Rig(wl2, P, dev, local_rank, rank, n, args, False)
+            for _ in range(P):
+                rig2.step()
+            rig2.sync()
+            dt2 = rig2.timed(args.steps, args.warmup)
+            st2 = rig2.ctxs[0].stats()
+            _, c2 = rig2.ctxs[0].trace(W, H, counting=True)
+            result["other_mesh"] = {"mesh": wl2.mesh_label, "value": st2.rays_total * args.steps / dt2 / 1e6, "unit": "Mrays/s", "ms_per_step": dt2 / args.steps * 1e3,
+                                    "rays_per_frame": {"primary": st2.rays_primary, "secondary": st2.rays_secondary, "shadow": st2.rays_shadow},
+                                    "mean_node_visits_per_ray": c2.node_visits / max(1, c2.closest_rays), "mean_tri_tests_per_ray": c2.tri_tests / max(1, c2.closest_rays),
+                                    "mean_node_visits_per_shadow_ray": c2.node_visits_shadow / max(1, c2.rays_shadow)}
+            rig2.close()
         if n == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
         else:
@@ -324,8 +438,6 @@ def main():
     if collective:
         dist.barrier()
         dist.destroy_process_group()
-    for c in ctxs:
-        c.close()
 
 
 if __name__ == "__main__":

@@ -120,16 +120,14 @@ int main(int argc, char** argv) {
     std::vector<float> image;
     float timeParam = 0.f;
     if (inFlight > 1) {
-      // Frames in flight, as the reference's swapchain loop has them (src/main.cpp:2905-2967): one Renderer (context,
-      // scene replica, pinned output) per frame in flight; a frame is submitted, and collected when its Renderer comes
+      // Frames in flight, as the reference's swapchain loop has them (src/main.cpp:2905-2967): one Renderer (frame slot:
+      // instances/TLAS, uniforms, queues, pinned output) per frame in flight on ONE shared scene; a frame is submitted, and collected when its Renderer comes
       // round again.  The pixels of every frame land in host memory, so the rate below includes the PCIe copy.
       std::vector<std::unique_ptr<rthost::Renderer>> ring;
       ring.push_back(nullptr);
       for (int k = 1; k < inFlight; k++) {
-        ring.emplace_back(new rthost::Renderer(device));
-        ring[k]->uploadGeometry(geometry);
+        ring.emplace_back(new rthost::Renderer(renderer));   // a frame slot on the shared scene: no second copy of geometry, BLAS or cube map
         ring[k]->setInstances(makeInstances(), false);
-        ring[k]->setSkybox(sky, sw, sh);
         ring[k]->setUniforms(uniformStructure);
       }
       auto at = [&](int k) -> rthost::Renderer& { return k == 0 ? renderer : *ring[k]; };

@@ -14,7 +14,8 @@
  *   - the caller owns every host array; the library copies on upload (as copyData does,
  *     src/main.cpp:203-219).  Handles are opaque; destroy is explicit.
  *   - one context drives one GPU and is not re-entrant (the reference is single-threaded with one
- *     queue and a blocking fence after every build/upload).
+ *     queue and a blocking fence after every build/upload); the contexts of one scene family (rt_create_frame_slot)
+ *     are driven from one host thread as well.
  *   - plain pointers and sizes only; no torch / HIP types in signatures (streams are void*).
  */
 #ifndef RT_API_H
@@ -110,6 +111,14 @@ typedef struct rt_stats {
 
 /* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */
 int rt_create(rt_ctx** out_ctx, int device_id);
+/* A second (third, ...) frame in flight on the same GPU: a context that SHARES the parent's scene — geometry, BLAS, cube map,
+ * everything rt_upload_geometry / rt_build_blas / rt_set_skybox created, before or after this call — and owns only what one
+ * frame needs: its instance records and TLAS, its uniform block, its ray queues, counters and stream.  This is the
+ * reference's per-swapchain-image state (command buffer, fence, semaphores: src/main.cpp:2597, 2740-2749) next to its
+ * shared buffers and acceleration structures.  Scene-building calls on ANY context of the family wait for the frames of
+ * all of them, rebuild the shared scene and invalidate every slot's TLAS (call rt_set_instances again).  At most 16
+ * contexts share a scene; rt_destroy on the last one frees it. */
+int rt_create_frame_slot(rt_ctx* parent, rt_ctx** out_ctx);
 /* Cleanup (src/main.cpp:2977-3060). */
 void rt_destroy(rt_ctx* ctx);
 
@@ -124,7 +133,9 @@ int rt_build_blas(rt_ctx* ctx, int mesh);
 
 /* createInstance + createTLAS (src/main.cpp:538-793; called :1818-1835 with update=false and every
  * frame :2848-2861 with update=true).  update!=0 keeps the TLAS topology and refits boxes (Vulkan
- * UPDATE mode, src=dst); it requires the same instance count as the last build. */
+ * UPDATE mode, src=dst); it requires the same instance count as the last build.  Waits for THIS context's pending frame
+ * (the records it reads are rewritten), then returns without waiting for the device: the records travel on the
+ * context's stream and the next frame is ordered behind them (the reference blocks on a fence here, src/main.cpp:772-778). */
 int rt_set_instances(rt_ctx* ctx, const rt_instance* instances, int n, int update);
 
 /* Uniform buffer copyData (src/main.cpp:1887-1889, 2901-2903). */

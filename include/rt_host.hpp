@@ -168,6 +168,11 @@ class Renderer {
     // runs ~8 % faster with 6 workgroups per CU; the library default (4) is tuned for several frames in flight
     check(rt_set_param(ctx_, "trace_blocks_per_cu", 6), "rt_set_param");
   }
+  // one more frame in flight on the same GPU: shares `scene`'s geometry, BLAS and cube map (rt_create_frame_slot)
+  explicit Renderer(Renderer& scene) {
+    int r = rt_create_frame_slot(scene.ctx_, &ctx_);
+    if (r) throwExceptionRtAPI(r, "rt_create_frame_slot", nullptr);
+  }
   ~Renderer() { rt_destroy(ctx_); }
   Renderer(const Renderer&) = delete;
   Renderer& operator=(const Renderer&) = delete;

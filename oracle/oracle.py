@@ -19,33 +19,51 @@ def build(force=False):
     return so
 
 
+def _bind(L):
+    L.orc_create.restype = C.c_void_p
+    L.orc_destroy.argtypes = [C.c_void_p]
+    L.orc_set_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+    L.orc_set_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_set_uniforms.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_set_skybox.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
+    L.orc_intersect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.orc_hit_attributes.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
+    L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    L.orc_jitter.argtypes = [C.c_float, C.c_float, C.c_float]
+    L.orc_jitter.restype = C.c_float
+    L.orc_sin.argtypes = [C.c_double]
+    L.orc_sin.restype = C.c_double
+    L.orc_pow100.argtypes = [C.c_float]
+    L.orc_pow100.restype = C.c_float
+    L.orc_invert_affine.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_sample_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_tri_test.argtypes = [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
+    L.orc_bounce_step.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_primary_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    return L
+
+
 def lib():
     global _LIB
     if _LIB is None:
-        L = C.CDLL(build())
-        L.orc_create.restype = C.c_void_p
-        L.orc_destroy.argtypes = [C.c_void_p]
-        L.orc_set_geometry.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
-        L.orc_set_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_set_uniforms.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_set_skybox.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int]
-        L.orc_intersect.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
-        L.orc_hit_attributes.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p]
-        L.orc_render.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
-        L.orc_jitter.argtypes = [C.c_float, C.c_float, C.c_float]
-        L.orc_jitter.restype = C.c_float
-        L.orc_sin.argtypes = [C.c_double]
-        L.orc_sin.restype = C.c_double
-        L.orc_pow100.argtypes = [C.c_float]
-        L.orc_pow100.restype = C.c_float
-        L.orc_invert_affine.argtypes = [C.c_void_p, C.c_void_p]
-        L.orc_sample_sky.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_tri_test.argtypes = [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
-        L.orc_bounce_step.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
-        L.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
-        L.orc_primary_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
-        _LIB = L
+        _LIB = _bind(C.CDLL(build()))
     return _LIB
+
+
+_NATIVE = None
+
+
+def lib_native():
+    """The -O3 -march=native build (bench.py's cpu_baseline): always compiled on the machine that runs it."""
+    global _NATIVE
+    if _NATIVE is None:
+        so = os.path.join(_HERE, "librt_oracle_native.so")
+        if os.path.exists(so):
+            os.remove(so)                     # a copy built on another CPU may hold instructions this one lacks
+        subprocess.check_call(["make", "-C", _HERE, "librt_oracle_native.so"], stdout=subprocess.DEVNULL)
+        _NATIVE = _bind(C.CDLL(so))
+    return _NATIVE
 
 
 def _ptr(a):
@@ -53,8 +71,8 @@ def _ptr(a):
 
 
 class OracleScene:
-    def __init__(self):
-        self.L = lib()
+    def __init__(self, native=False):
+        self.L = lib_native() if native else lib()
         self.h = C.c_void_p(self.L.orc_create())
         self._keep = []
 

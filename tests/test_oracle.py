@@ -253,6 +253,30 @@ def test_oracle_frames_match_their_committed_hashes():
         assert got[name]["sha256"] == want[name]["sha256"], name
 
 
+def test_native_build_of_the_oracle_is_bit_identical():
+    """bench.py's cpu_baseline times the oracle built -O3 -march=native (oracle/Makefile librt_oracle_native.so, compiled on the
+    machine that runs it).  Same source, same -ffp-contract=off: the frames must equal the committed hashes of the portable
+    build bit for bit — the canonical arithmetic does not depend on optimisation level or instruction set."""
+    import hashlib
+    import importlib.util
+    import json
+    from oracle import oracle
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_oracle_images", os.path.join(here, "make_oracle_images.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    want = json.load(open(os.path.join(here, "oracle_images.json")))
+    for name, (sp, W, H) in mod.cases().items():
+        S = oracle.OracleScene(native=True)
+        S.set_geometry(sp.geom.verts, sp.geom.idx, sp.geom.ranges)
+        S.set_instances([sp.instances[i].tobytes() for i in range(len(sp.instances))])
+        S.set_uniforms(sp.uniforms.tobytes())
+        S.set_skybox(sp.sky)
+        img, rc = S.render(W, H)
+        assert hashlib.sha256(np.ascontiguousarray(img, np.float32).tobytes()).hexdigest() == want[name]["sha256"], name
+        assert [int(x) for x in rc] == want[name]["rays"], name
+
+
 def test_division_free_over_255_equals_ieee_division(tmp_path):
     """kernels.hip computes x/255 in the cube-map filter with two fmas instead of an IEEE division; the oracle divides.
     tools/check_div255.c proves both agree for every binary32 x in [0, 256] (exhaustive with stride 1); here every

@@ -33,7 +33,7 @@ class RtStats(C.Structure):
         return self.rays_primary + self.rays_secondary + self.rays_shadow
 
 
-EXPORTS = ["rt_create", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
+EXPORTS = ["rt_create", "rt_create_frame_slot", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
            "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
            "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_debug_sizing", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
@@ -46,6 +46,7 @@ def lib():
         L = _native.load_rt()
         vp = C.c_void_p
         L.rt_create.argtypes = [C.POINTER(vp), C.c_int]
+        L.rt_create_frame_slot.argtypes = [vp, C.POINTER(vp)]
         L.rt_destroy.argtypes = [vp]
         L.rt_destroy.restype = None
         L.rt_upload_geometry.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_int]
@@ -90,13 +91,21 @@ def _p(a):
 class RtContext:
     """One context = one GPU (rt_create).  Methods map 1:1 onto the C ABI."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _parent=None):
         self.L = lib()
         h = C.c_void_p()
-        rc = self.L.rt_create(C.byref(h), device)
+        if _parent is not None:
+            rc = self.L.rt_create_frame_slot(_parent.h, C.byref(h))
+        else:
+            rc = self.L.rt_create(C.byref(h), device)
         if rc:
-            raise RtError(rc, "rt_create", self.L.rt_last_error(None).decode())
+            raise RtError(rc, "rt_create_frame_slot" if _parent is not None else "rt_create", self.L.rt_last_error(None).decode())
         self.h = h
+
+    def frame_slot(self):
+        """rt_create_frame_slot: a context for one more frame in flight that shares this context's scene (geometry, BLAS,
+        cube map) and owns its instances/TLAS, uniforms, queues and stream."""
+        return RtContext(_parent=self)
 
     def _chk(self, rc, fn):
         if rc:

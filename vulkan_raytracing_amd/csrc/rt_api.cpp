@@ -51,12 +51,16 @@ enum { CAT_RAYGEN = 0, CAT_TRACE, CAT_SHADE, CAT_SHADOW, CAT_RESOLVE, CAT_FRAME,
 
 }  // namespace
 
-struct rt_ctx {
+// Everything a frame only READS, shared by the frame slots of one GPU: geometry (bindings 2/3), the linked BLAS nodes and
+// triangle packets, the cube map (binding 5).  The reference shares exactly these across its swapchain images and duplicates
+// only the per-image command buffer, fence and semaphores (src/main.cpp:2597, 2740-2749); a context created with
+// rt_create_frame_slot is that per-image part.  Each slot owns a TLAS region behind the BLAS nodes (one base pointer for
+// the kernels): slot k's TLAS nodes start at n_blas_nodes + k * tlas_cap.
+constexpr int MAX_SLOTS = 16;          // = MAX_TAILS_IN_FLIGHT: frame slots per scene
+struct Scene {
   int device = 0;
-  hipStream_t stream = nullptr;
-  std::string error;
-  std::string info;
-  int n_cu = 0;
+  std::vector<rt_ctx*> members;        // every context that renders from this scene
+  uint32_t slot_mask = 0;              // TLAS regions in use
 
   // geometry (bindings 2/3)
   std::vector<float> h_verts;
@@ -65,34 +69,53 @@ struct rt_ctx {
   uint32_t* d_idx = nullptr;
   std::vector<Mesh> meshes;
   bool blas_linked = false;
+  // linked acceleration structures: BLAS part [0, n_blas*), then MAX_SLOTS TLAS regions of tlas_cap entries each
+  std::vector<BvhNodeQ> h_blasq;
   BvhNodeQ* d_blas_nodes = nullptr;
-  Bvh4Node* d_nodes4 = nullptr;     // BLAS BVH4 nodes followed by the TLAS BVH4 nodes
-  size_t cap_nodes4 = 0, n_blas4 = 0;
   std::vector<Bvh4Node> h_blas4;
-  WideNodeQ* d_wide = nullptr;      // 4-ary records of the same trees, same numbering as d_blas_nodes
+  Bvh4Node* d_nodes4 = nullptr;        // variant 1
   std::vector<WideNodeQ> h_wide;
-  uint32_t ovf_stride = STACK_OVF, ovf_alloc_stride = 0;
-  int ovf_alloc_blocks = 0;
+  WideNodeQ* d_wide = nullptr;         // variant 2, same numbering as d_blas_nodes
   float4* d_tris = nullptr;
-  size_t n_blas_nodes = 0, n_tris = 0;
+  size_t n_blas_nodes = 0, n_blas4 = 0, n_tris = 0;
+  uint32_t tlas_cap = 1024;            // TLAS nodes per slot (grows when a sole owner needs more)
+  bool arrays_ready = false;           // device node arrays allocated for (n_blas*, tlas_cap, variant)
+  int variant = 0;                     // traversal variant the arrays were linked for
 
-  // instances / TLAS (binding 0)
+  // cube map (binding 5)
+  uchar4* d_sky = nullptr;
+  int sky_w = 0, sky_h = 0;
+};
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string error;
+  std::string info;
+  int n_cu = 0;
+  Scene* scene = nullptr;
+  int slot = 0;                  // this context's TLAS region in the scene's node arrays
+
+  // instances / TLAS (binding 0) of this slot
   std::vector<rt_instance> h_inst;
-  std::vector<InstanceDev> h_inst_dev;
   BuiltBvh tlas;
   Bvh4 tlas4;
   bool tlas_valid = false;
   InstanceDev* d_inst = nullptr;
-  std::vector<BvhNodeQ> h_blasq;    // host copy of the linked BLAS nodes (re-uploaded when the array grows)
-  size_t cap_nodesq = 0;
-  float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
   size_t cap_inst = 0;
+  float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
+  uint32_t ovf_stride = STACK_OVF, ovf_alloc_stride = 0;
+  int ovf_alloc_blocks = 0;
+  // per-frame TLAS update without a host stall: records are assembled in pinned memory and copied on the context's stream;
+  // a frame on another stream waits for ev_upload on the device
+  char* h_stage = nullptr;
+  size_t stage_bytes = 0;
+  hipEvent_t ev_upload = nullptr;
+  bool upload_pending = false;
 
-  // uniforms (binding 1), cube map (binding 5)
+  // uniforms (binding 1)
   UniformsDev uni{};
   bool have_uni = false;
-  uchar4* d_sky = nullptr;
-  int sky_w = 0, sky_h = 0;
 
   // frame state
   FrameDev frame{};
@@ -204,10 +227,14 @@ int rt::tail_grid(int n_cu, int resident_blocks_per_cu) {
 
 namespace {
 
+// concatenate every built mesh into one node array / one packet array with global references (host side), then
+// (re)allocate the device arrays: BLAS part + MAX_SLOTS TLAS regions, and upload the BLAS part
+int alloc_scene_arrays(rt_ctx* c);
+
 int link_blas(rt_ctx* c) {
-  // concatenate every built mesh into one node array / one packet array with global references
+  Scene* S = c->scene;
   size_t nn = 0, nt = 0, nn4 = 0;
-  for (auto& m : c->meshes) {
+  for (auto& m : S->meshes) {
     if (!m.built) continue;
     m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt; m.node_base4 = (int32_t)nn4;
     nn += m.gpu_built ? m.qnodes.size() : m.bvh.nodes.size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
@@ -215,7 +242,7 @@ int link_blas(rt_ctx* c) {
   std::vector<BvhNodeQ> nodes(nn);
   std::vector<Bvh4Node> nodes4(nn4);
   std::vector<TriPacket> tris(nt);
-  for (auto& m : c->meshes) {
+  for (auto& m : S->meshes) {
     if (!m.built) continue;
     if (!m.gpu_built) quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
     for (size_t i = 0; i < m.qnodes.size(); i++) {
@@ -243,100 +270,145 @@ int link_blas(rt_ctx* c) {
     m.levels = bvh2_levels(m.qnodes.data(), m.qnodes.size(), 0);
     if (m.levels < 0) return fail(c, RT_ERR_DEVICE, "BLAS builder produced a node graph that is not a tree");
   }
-  std::vector<WideNodeQ> wide(c->cfg.variant == 2 ? nn : 0);   // only the variant that walks them pays for them
-  if (c->cfg.variant == 2)
-    for (auto& m : c->meshes)
+  S->variant = c->cfg.variant;
+  std::vector<WideNodeQ> wide(S->variant == 2 ? nn : 0);   // only the variant that walks them pays for them
+  if (S->variant == 2)
+    for (auto& m : S->meshes)
       if (m.built && !m.qnodes.empty()) widen_bvh2(&nodes[m.node_base], m.qnodes.size(), m.node_base, &wide[m.node_base]);
-  c->h_wide.swap(wide);
-  if (c->d_wide) { HIP_TRY(c, hipFree(c->d_wide)); c->d_wide = nullptr; }
-  if (c->d_blas_nodes) { HIP_TRY(c, hipFree(c->d_blas_nodes)); c->d_blas_nodes = nullptr; c->cap_nodesq = 0; }
-  if (c->d_tris) { HIP_TRY(c, hipFree(c->d_tris)); c->d_tris = nullptr; }
-  if (c->d_nodes4) { HIP_TRY(c, hipFree(c->d_nodes4)); c->d_nodes4 = nullptr; c->cap_nodes4 = 0; }
-  c->h_blas4.swap(nodes4); c->n_blas4 = nn4;
-  HIP_TRY(c, hipMalloc((void**)&c->d_tris, std::max<size_t>(1, nt) * sizeof(TriPacket)));
-  c->h_blasq.swap(nodes);
-  if (nt) HIP_TRY(c, hipMemcpy(c->d_tris, tris.data(), nt * sizeof(TriPacket), hipMemcpyHostToDevice));
-  c->n_blas_nodes = nn; c->n_tris = nt;
-  c->blas_linked = true;
+  S->h_wide.swap(wide);
+  S->h_blas4.swap(nodes4); S->n_blas4 = nn4;
+  S->h_blasq.swap(nodes);
+  S->n_blas_nodes = nn; S->n_tris = nt;
+  if (S->d_tris) { HIP_TRY(c, hipFree(S->d_tris)); S->d_tris = nullptr; }
+  HIP_TRY(c, hipMalloc((void**)&S->d_tris, std::max<size_t>(1, nt) * sizeof(TriPacket)));
+  if (nt) HIP_TRY(c, hipMemcpy(S->d_tris, tris.data(), nt * sizeof(TriPacket), hipMemcpyHostToDevice));
+  S->arrays_ready = false;
+  int r = alloc_scene_arrays(c); if (r) return r;
+  S->blas_linked = true;
   return RT_OK;
 }
 
-int upload_instances(rt_ctx* c) {
-  const size_t n = c->h_inst_dev.size();
+int alloc_scene_arrays(rt_ctx* c) {
+  Scene* S = c->scene;
+  const size_t regions = (size_t)MAX_SLOTS * S->tlas_cap;
+  if (S->d_blas_nodes) { HIP_TRY(c, hipFree(S->d_blas_nodes)); S->d_blas_nodes = nullptr; }
+  if (S->d_nodes4) { HIP_TRY(c, hipFree(S->d_nodes4)); S->d_nodes4 = nullptr; }
+  if (S->d_wide) { HIP_TRY(c, hipFree(S->d_wide)); S->d_wide = nullptr; }
+  HIP_TRY(c, hipMalloc((void**)&S->d_blas_nodes, (S->n_blas_nodes + regions) * sizeof(BvhNodeQ)));
+  if (S->n_blas_nodes) HIP_TRY(c, hipMemcpy(S->d_blas_nodes, S->h_blasq.data(), S->n_blas_nodes * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
+  if (S->n_blas4) {   // quad traversal (host-built meshes only)
+    HIP_TRY(c, hipMalloc((void**)&S->d_nodes4, (S->n_blas4 + regions) * sizeof(Bvh4Node)));
+    HIP_TRY(c, hipMemcpy(S->d_nodes4, S->h_blas4.data(), S->n_blas4 * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+  }
+  if (S->variant == 2) {
+    HIP_TRY(c, hipMalloc((void**)&S->d_wide, (S->n_blas_nodes + regions) * sizeof(WideNodeQ)));
+    if (S->n_blas_nodes) HIP_TRY(c, hipMemcpy(S->d_wide, S->h_wide.data(), S->n_blas_nodes * sizeof(WideNodeQ), hipMemcpyHostToDevice));
+  }
+  S->arrays_ready = true;
+  return RT_OK;
+}
+
+// first node of this slot's TLAS region in the quantized / wide arrays and in the BVH4 array
+inline size_t tlas_base(const rt_ctx* c) { return c->scene->n_blas_nodes + (size_t)c->slot * c->scene->tlas_cap; }
+inline size_t tlas_base4(const rt_ctx* c) { return c->scene->n_blas4 + (size_t)c->slot * c->scene->tlas_cap; }
+
+// Instance records and this slot's TLAS nodes go to the device WITHOUT stalling the host: they are assembled in pinned
+// memory and copied on the context's stream; ev_upload orders frames on other streams behind the copies.  (The reference
+// allocates two buffers, submits and blocks on vkWaitForFences every frame, src/main.cpp:672-696, 752-778.)
+int upload_instances(rt_ctx* c, const std::vector<InstanceDev>& inst_dev) {
+  Scene* S = c->scene;
+  const size_t n = inst_dev.size();
+  std::vector<BvhNodeQ> tq;
+  quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
+  const size_t need = std::max(tq.size(), c->tlas4.nodes.size());
+  if (need > S->tlas_cap) {
+    // a sole owner may grow the regions (nothing else reads the arrays); with several slots the arrays cannot move
+    if (S->members.size() > 1)
+      return fail(c, RT_ERR_INVALID_ARGUMENT, "TLAS of " + std::to_string(need) + " nodes exceeds the " + std::to_string(S->tlas_cap) +
+                                                 " a frame slot of a shared scene can hold: set the instances before creating frame slots");
+    S->tlas_cap = (uint32_t)((need + 1023) & ~(size_t)1023);
+    int r = alloc_scene_arrays(c); if (r) return r;
+  }
   if (n > c->cap_inst) {
     if (c->d_inst) HIP_TRY(c, hipFree(c->d_inst));
+    c->d_inst = nullptr; c->cap_inst = 0;
     HIP_TRY(c, hipMalloc((void**)&c->d_inst, n * sizeof(InstanceDev)));
     c->cap_inst = n;
   }
-  const size_t needq = c->n_blas_nodes + c->tlas.nodes.size();
-  if (needq > c->cap_nodesq || !c->d_blas_nodes) {
-    if (c->d_blas_nodes) HIP_TRY(c, hipFree(c->d_blas_nodes));
-    c->cap_nodesq = needq + 64;
-    HIP_TRY(c, hipMalloc((void**)&c->d_blas_nodes, c->cap_nodesq * sizeof(BvhNodeQ)));
-    if (c->n_blas_nodes) HIP_TRY(c, hipMemcpy(c->d_blas_nodes, c->h_blasq.data(), c->n_blas_nodes * sizeof(BvhNodeQ), hipMemcpyHostToDevice));
-    if (c->d_wide) { HIP_TRY(c, hipFree(c->d_wide)); c->d_wide = nullptr; }
+  const size_t base = tlas_base(c), base4 = tlas_base4(c);
+  for (auto& nd : tq) {   // interior links are relative to the TLAS: rebase them to this slot's region
+    if (nd.child0 >= 0) nd.child0 += (int32_t)base;
+    if (nd.child1 >= 0) nd.child1 += (int32_t)base;
   }
-  if (!c->d_wide && c->cfg.variant == 2) {
-    HIP_TRY(c, hipMalloc((void**)&c->d_wide, c->cap_nodesq * sizeof(WideNodeQ)));
-    if (c->n_blas_nodes) HIP_TRY(c, hipMemcpy(c->d_wide, c->h_wide.data(), c->n_blas_nodes * sizeof(WideNodeQ), hipMemcpyHostToDevice));
+  std::vector<Bvh4Node> t4;
+  if (S->d_nodes4) {
+    t4 = c->tlas4.nodes;
+    for (auto& nd : t4)
+      for (int k = 0; k < 4; k++)
+        if (nd.c[k].ref >= 0 && nd.c[k].ref != 0x7FFFFFFF) nd.c[k].ref += (int32_t)base4;
   }
-  // stream-ordered so a per-frame update never stalls the host on a fence (the reference blocks on
-  // vkWaitForFences every frame, src/main.cpp:772-778)
-  HIP_TRY(c, hipMemcpyAsync(c->d_inst, c->h_inst_dev.data(), n * sizeof(InstanceDev), hipMemcpyHostToDevice, c->stream));
-  // quad traversal: one node array (BLAS nodes, then TLAS nodes with their interior links rebased)
-  const size_t need4 = c->n_blas4 + c->tlas4.nodes.size();
-  if (need4 > c->cap_nodes4) {
-    if (c->d_nodes4) HIP_TRY(c, hipFree(c->d_nodes4));
-    c->cap_nodes4 = need4 + 64;
-    HIP_TRY(c, hipMalloc((void**)&c->d_nodes4, c->cap_nodes4 * sizeof(Bvh4Node)));
-    if (c->n_blas4) HIP_TRY(c, hipMemcpy(c->d_nodes4, c->h_blas4.data(), c->n_blas4 * sizeof(Bvh4Node), hipMemcpyHostToDevice));
+  std::vector<WideNodeQ> tw(S->variant == 2 ? tq.size() : 0);
+  if (S->variant == 2) widen_bvh2(tq.data(), tq.size(), (int32_t)base, tw.data());
+  // pinned staging: [instances][quantized TLAS][BVH4 TLAS][wide TLAS]
+  const size_t b_inst = n * sizeof(InstanceDev), b_q = tq.size() * sizeof(BvhNodeQ), b_4 = t4.size() * sizeof(Bvh4Node), b_w = tw.size() * sizeof(WideNodeQ);
+  const size_t total = b_inst + b_q + b_4 + b_w;
+  if (total > c->stage_bytes) {
+    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
+    c->h_stage = nullptr; c->stage_bytes = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, total + 4096, hipHostMallocDefault));
+    c->stage_bytes = total + 4096;
   }
-  std::vector<Bvh4Node> t4 = c->tlas4.nodes;
-  for (auto& nd : t4)
-    for (int k = 0; k < 4; k++)
-      if (nd.c[k].ref >= 0 && nd.c[k].ref != 0x7FFFFFFF) nd.c[k].ref += (int32_t)c->n_blas4;
-  HIP_TRY(c, hipMemcpyAsync(c->d_nodes4 + c->n_blas4, t4.data(), t4.size() * sizeof(Bvh4Node), hipMemcpyHostToDevice, c->stream));
-  std::vector<BvhNodeQ> tq;
-  quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
-  for (auto& nd : tq) {   // interior links are relative to the TLAS: rebase them behind the BLAS nodes
-    if (nd.child0 >= 0) nd.child0 += (int32_t)c->n_blas_nodes;
-    if (nd.child1 >= 0) nd.child1 += (int32_t)c->n_blas_nodes;
-  }
-  HIP_TRY(c, hipMemcpyAsync(c->d_blas_nodes + c->n_blas_nodes, tq.data(), tq.size() * sizeof(BvhNodeQ), hipMemcpyHostToDevice, c->stream));
-  std::vector<WideNodeQ> tw(c->cfg.variant == 2 ? tq.size() : 0);
-  if (c->cfg.variant == 2) {
-    widen_bvh2(tq.data(), tq.size(), (int32_t)c->n_blas_nodes, tw.data());
-    HIP_TRY(c, hipMemcpyAsync(c->d_wide + c->n_blas_nodes, tw.data(), tw.size() * sizeof(WideNodeQ), hipMemcpyHostToDevice, c->stream));
-  }
-  HIP_TRY(c, hipStreamSynchronize(c->stream));  // host vectors may be rewritten by the next call
+  if (!c->ev_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
+  char* st = c->h_stage;
+  memcpy(st, inst_dev.data(), b_inst);
+  memcpy(st + b_inst, tq.data(), b_q);
+  if (b_4) memcpy(st + b_inst + b_q, t4.data(), b_4);
+  if (b_w) memcpy(st + b_inst + b_q + b_4, tw.data(), b_w);
+  HIP_TRY(c, hipMemcpyAsync(c->d_inst, st, b_inst, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(S->d_blas_nodes + base, st + b_inst, b_q, hipMemcpyHostToDevice, c->stream));
+  if (b_4) HIP_TRY(c, hipMemcpyAsync(S->d_nodes4 + base4, st + b_inst + b_q, b_4, hipMemcpyHostToDevice, c->stream));
+  if (b_w) HIP_TRY(c, hipMemcpyAsync(S->d_wide + base, st + b_inst + b_q + b_4, b_w, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipEventRecord(c->ev_upload, c->stream));
+  c->upload_pending = true;
   return RT_OK;
 }
 
 SceneDev scene_dev(const rt_ctx* c) {
+  const Scene* S = c->scene;
   SceneDev s{};
-  s.nodes4 = c->d_nodes4; s.tlas_root4 = (int)c->n_blas4;
-  s.wide_nodes = c->d_wide; s.ovf_stride = c->ovf_stride;
-  s.blas_nodes = c->d_blas_nodes; s.tlas_root = (int)c->n_blas_nodes; s.tris = c->d_tris; s.inst = c->d_inst;
-  s.verts = c->d_verts; s.idx = c->d_idx; s.sky = c->d_sky; s.n_inst = (int)c->h_inst_dev.size();
-  s.sky_w = c->sky_w; s.sky_h = c->sky_h;
+  s.nodes4 = S->d_nodes4; s.tlas_root4 = (int)tlas_base4(c);
+  s.wide_nodes = S->d_wide; s.ovf_stride = c->ovf_stride;
+  s.blas_nodes = S->d_blas_nodes; s.tlas_root = (int)tlas_base(c); s.tris = S->d_tris; s.inst = c->d_inst;
+  s.verts = S->d_verts; s.idx = S->d_idx; s.sky = S->d_sky; s.n_inst = (int)c->h_inst.size();
+  s.sky_w = S->sky_w; s.sky_h = S->sky_h;
   for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
   return s;
 }
 
 int collect_stats(rt_ctx* c);
 
-// Scene-changing calls wait for the frame this context still has in flight (the reference waits on the frame's fence
+// Calls that rewrite what a pending frame reads wait for that frame first (the reference waits on the frame's fence
 // before it touches the TLAS or the uniform buffer again, src/main.cpp:772-778).
 int quiesce(rt_ctx* c) {
   if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "a frame submitted with rt_trace_async is pending: call rt_trace_wait first");
   if (c->frame_pending) return collect_stats(c);
   return RT_OK;
 }
+// Calls that rewrite the SHARED scene wait for the frames of every slot that renders from it.
+int quiesce_scene(rt_ctx* c) {
+  for (rt_ctx* m : c->scene->members) {
+    if (m->async_pending) return fail(c, RT_ERR_NOT_READY, "a frame slot of this scene has a frame pending (rt_trace_async): collect it with rt_trace_wait first");
+    if (m->frame_pending) { int r = collect_stats(m); if (r) { if (m != c) c->error = m->error; return r; } }
+    if (m->upload_pending) { HIP_TRY(c, hipEventSynchronize(m->ev_upload)); m->upload_pending = false; }
+  }
+  return RT_OK;
+}
+// the linked arrays changed: every slot has to set its instances again
+void invalidate_tlas(Scene* S) { for (rt_ctx* m : S->members) m->tlas_valid = false; }
 
 int ready_to_trace(rt_ctx* c) {
-  if (!c->d_verts) return fail(c, RT_ERR_NOT_READY, "rt_upload_geometry has not been called");
+  if (!c->scene->d_verts) return fail(c, RT_ERR_NOT_READY, "rt_upload_geometry has not been called");
   if (!c->tlas_valid) return fail(c, RT_ERR_NOT_READY, "rt_set_instances has not been called");
-  if (!c->blas_linked) { int r = link_blas(c); if (r) return r; }
   return RT_OK;
 }
 
@@ -420,6 +492,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   c->last_max_bounce = u.max_bounce_count;
   c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
   c->last_empty = rows == 0;
+  // the instance records / TLAS nodes of this slot were copied on the context's stream: a frame on another stream waits on the device
+  if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload, 0));
   if (rows == 0) { HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s)); return RT_OK; }
   {
     Span frame_span(c, CAT_FRAME, s);
@@ -463,6 +537,7 @@ int collect_stats(rt_ctx* c) {
   // k_resolve has written the frame's statistics block to host-mapped memory: nothing to copy.  (A device-to-host
   // copy of the counters here, behind the pixel copy of rt_trace_async, serialised the frames of other contexts.)
   HIP_TRY(c, hipStreamSynchronize(c->frame_stream));
+  c->upload_pending = false;   // the frame waited for the copies: staging and device records may be rewritten
   const unsigned long long* hs = c->h_stats;
   rt_stats st{};
   st.rays_primary = c->last_primary;
@@ -527,7 +602,7 @@ extern "C" {
 
 int rt_abi_version(void) { return 3; }   // 2: rt_trace_async / rt_trace_wait, rt_stats::ms_tail; 3: rt_stats::tail_faults, rt_debug_sizing
 
-int rt_create(rt_ctx** out_ctx, int device_id) {
+static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
   *out_ctx = nullptr;
   int n = 0;
@@ -540,6 +615,11 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   HIP_TRY(nullptr, hipGetDeviceProperties(&prop, device_id));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     return fail(nullptr, RT_ERR_NO_DEVICE, std::string("device is ") + prop.gcnArchName + ", this library contains gfx950 code only");
+  int slot = 0;
+  if (parent) {
+    while (slot < MAX_SLOTS && (parent->scene->slot_mask >> slot & 1u)) slot++;
+    if (slot == MAX_SLOTS) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "a scene holds at most " + std::to_string(MAX_SLOTS) + " frame slots");
+  }
   rt_ctx* c = new rt_ctx();
   c->device = device_id;
   c->n_cu = prop.multiProcessorCount;
@@ -556,8 +636,25 @@ int rt_create(rt_ctx** out_ctx, int device_id) {
   if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TRACE_VARIANT")) { const int v = atoi(env); c->cfg.variant = (v >= 0 && v <= 2) ? v : 0; }
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
+  if (parent) {
+    c->scene = parent->scene;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->out_rgba8 = parent->out_rgba8;
+  } else {
+    c->scene = new Scene();
+    c->scene->device = device_id;
+  }
+  c->slot = slot;
+  c->scene->slot_mask |= 1u << slot;
+  c->scene->members.push_back(c);
   *out_ctx = c;
   return RT_OK;
+}
+
+int rt_create(rt_ctx** out_ctx, int device_id) { return create_context(out_ctx, device_id, nullptr); }
+
+int rt_create_frame_slot(rt_ctx* parent, rt_ctx** out_ctx) {
+  if (!parent) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "parent context is NULL");
+  return create_context(out_ctx, parent->device, parent);
 }
 
 void rt_destroy(rt_ctx* c) {
@@ -565,14 +662,24 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_wide, c->d_nodes4, c->d_verts, c->d_idx, c->d_blas_nodes, c->d_tris, c->d_inst, c->d_sky, c->d_out_own, c->d_counters, c->d_ovf,
+  void* ptrs[] = {c->d_inst, c->d_out_own, c->d_counters, c->d_ovf,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
   if (c->h_out_pinned) hipHostFree(c->h_out_pinned);
   if (c->h_stats) hipHostFree(c->h_stats);
+  if (c->h_stage) hipHostFree(c->h_stage);
+  if (c->ev_upload) hipEventDestroy(c->ev_upload);
   for (auto e : c->ev_pool) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
+  Scene* S = c->scene;
+  S->members.erase(std::remove(S->members.begin(), S->members.end(), c), S->members.end());
+  S->slot_mask &= ~(1u << c->slot);
+  if (S->members.empty()) {   // the last context of a scene takes the shared arrays with it
+    void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky};
+    for (void* p : sp) if (p) hipFree(p);
+    delete S;
+  }
   delete c;
 }
 
@@ -583,7 +690,8 @@ int rt_upload_geometry(rt_ctx* c, const float* verts6, size_t n_floats, const ui
                        const rt_mesh_range* ranges, int n_meshes) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!verts6 || !idx || !ranges || n_meshes <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "null geometry pointers or no meshes");
-  { int q = quiesce(c); if (q) return q; }
+  { int q = quiesce_scene(c); if (q) return q; }
+  Scene* S = c->scene;
   if (n_floats % 6 != 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "vertex buffer must hold 6 floats per vertex");
   HIP_TRY(c, hipSetDevice(c->device));
   for (int m = 0; m < n_meshes; m++) {
@@ -594,33 +702,34 @@ int rt_upload_geometry(rt_ctx* c, const float* verts6, size_t n_floats, const ui
     for (uint64_t k = 0; k < 3ull * r.prim_count; k++)
       if (idx[r.first_index + k] >= nv) return fail(c, RT_ERR_INVALID_ARGUMENT, "index out of range in mesh " + std::to_string(m));
   }
-  c->h_verts.assign(verts6, verts6 + n_floats);
-  c->h_idx.assign(idx, idx + n_idx);
-  if (c->d_verts) HIP_TRY(c, hipFree(c->d_verts));
-  if (c->d_idx) HIP_TRY(c, hipFree(c->d_idx));
-  c->d_verts = nullptr; c->d_idx = nullptr;
-  HIP_TRY(c, hipMalloc((void**)&c->d_verts, std::max<size_t>(n_floats, 6) * sizeof(float)));
-  HIP_TRY(c, hipMalloc((void**)&c->d_idx, std::max<size_t>(n_idx, 3) * sizeof(uint32_t)));
-  HIP_TRY(c, hipMemcpy(c->d_verts, verts6, n_floats * sizeof(float), hipMemcpyHostToDevice));
-  HIP_TRY(c, hipMemcpy(c->d_idx, idx, n_idx * sizeof(uint32_t), hipMemcpyHostToDevice));
-  c->meshes.assign(n_meshes, Mesh{});
-  for (int m = 0; m < n_meshes; m++) c->meshes[m].range = ranges[m];
-  c->blas_linked = false; c->tlas_valid = false;
+  S->h_verts.assign(verts6, verts6 + n_floats);
+  S->h_idx.assign(idx, idx + n_idx);
+  if (S->d_verts) HIP_TRY(c, hipFree(S->d_verts));
+  if (S->d_idx) HIP_TRY(c, hipFree(S->d_idx));
+  S->d_verts = nullptr; S->d_idx = nullptr;
+  HIP_TRY(c, hipMalloc((void**)&S->d_verts, std::max<size_t>(n_floats, 6) * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void**)&S->d_idx, std::max<size_t>(n_idx, 3) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemcpy(S->d_verts, verts6, n_floats * sizeof(float), hipMemcpyHostToDevice));
+  HIP_TRY(c, hipMemcpy(S->d_idx, idx, n_idx * sizeof(uint32_t), hipMemcpyHostToDevice));
+  S->meshes.assign(n_meshes, Mesh{});
+  for (int m = 0; m < n_meshes; m++) S->meshes[m].range = ranges[m];
+  S->blas_linked = false; invalidate_tlas(S);
   return RT_OK;
 }
 
 int rt_build_blas(rt_ctx* c, int mesh) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
-  if (mesh < 0 || mesh >= (int)c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
-  { int q = quiesce(c); if (q) return q; }
-  Mesh& m = c->meshes[mesh];
+  Scene* S = c->scene;
+  if (mesh < 0 || mesh >= (int)S->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "mesh index out of range");
+  { int q = quiesce_scene(c); if (q) return q; }
+  Mesh& m = S->meshes[mesh];
   m.gpu_built = false;
   if (c->blas_builder == 1 && c->cfg.variant != 1 && m.range.prim_count >= 8) {
     // device build: LBVH straight from the uploaded vertex/index buffers; the result is downloaded once so that the
     // linker treats every mesh alike
     HIP_TRY(c, hipSetDevice(c->device));
     GpuBlas g; std::string err;
-    if (build_blas_gpu(c->d_verts + m.range.first_float, c->d_idx + m.range.first_index, m.range.prim_count, c->stream, g, err))
+    if (build_blas_gpu(S->d_verts + m.range.first_float, S->d_idx + m.range.first_index, m.range.prim_count, c->stream, g, err))
       return fail(c, RT_ERR_DEVICE, err);
     m.qnodes.resize(g.n_nodes); m.tris.resize(g.n_tris);
     hipError_t e1 = hipMemcpy(m.qnodes.data(), g.nodes, (size_t)g.n_nodes * sizeof(BvhNodeQ), hipMemcpyDeviceToHost);
@@ -631,33 +740,38 @@ int rt_build_blas(rt_ctx* c, int mesh) {
     m.bvh = BuiltBvh{}; m.bvh4 = Bvh4{};
     m.gpu_built = true;
   } else {
-    build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
+    build_blas(S->h_verts.data() + m.range.first_float, S->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
     collapse_bvh4(m.bvh, true, false, m.bvh4);
     m.bounds = m.bvh.bounds;
   }
   m.built = true;
-  c->blas_linked = false; c->tlas_valid = false;
+  S->blas_linked = false; invalidate_tlas(S);
   return RT_OK;
 }
 
 int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!inst || n <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "no instances");
-  { int q = quiesce(c); if (q) return q; }
+  { int q = quiesce(c); if (q) return q; }   // this slot's previous frame still reads the records below
   HIP_TRY(c, hipSetDevice(c->device));
+  Scene* S = c->scene;
+  if (c->upload_pending) { HIP_TRY(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; }   // staging is reused
   for (int i = 0; i < n; i++) {
-    if (inst[i].mesh >= c->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance references an unknown mesh");
-    if (!c->meshes[inst[i].mesh].built) return fail(c, RT_ERR_NOT_READY, "instance references a mesh whose BLAS is not built (rt_build_blas)");
+    if (inst[i].mesh >= S->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance references an unknown mesh");
+    if (!S->meshes[inst[i].mesh].built) return fail(c, RT_ERR_NOT_READY, "instance references a mesh whose BLAS is not built (rt_build_blas)");
   }
   if (update && (!c->tlas_valid || (int)c->h_inst.size() != n))
     return fail(c, RT_ERR_INVALID_ARGUMENT, "TLAS update needs a previous build with the same instance count");
-  if (!c->blas_linked) { int r = link_blas(c); if (r) return r; }
+  if (!S->blas_linked) {   // (re)linking moves the shared arrays: every slot of the scene has to be idle
+    int q = quiesce_scene(c); if (q) return q;
+    int r = link_blas(c); if (r) return r;
+  }
   c->h_inst.assign(inst, inst + n);
-  c->h_inst_dev.resize(n);
+  std::vector<InstanceDev> inst_dev(n);
   std::vector<Aabb> boxes(n);
   for (int i = 0; i < n; i++) {
-    InstanceDev& d = c->h_inst_dev[i];
-    const Mesh& m = c->meshes[inst[i].mesh];
+    InstanceDev& d = inst_dev[i];
+    const Mesh& m = S->meshes[inst[i].mesh];
     memcpy(d.o2w, inst[i].transform, sizeof(d.o2w));
     invert_affine(d.o2w, d.w2o);
     d.blas_root = m.node_base;
@@ -675,7 +789,7 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   // the quad traversal keeps its whole stack in LDS: bottom sentinel + TLAS + marker + deepest BLAS
   int blas_need = 0, blas_levels = 0;
   for (int i = 0; i < n; i++) {
-    const Mesh& m = c->meshes[inst[i].mesh];
+    const Mesh& m = S->meshes[inst[i].mesh];
     if (m.gpu_built && c->cfg.variant == 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "device-built BLAS is not traversed by trace_variant 1: set trace_variant before rt_build_blas or use blas_builder 0");
     blas_need = std::max(blas_need, m.bvh4.stack_need);
     blas_levels = std::max(blas_levels, m.levels);
@@ -690,8 +804,9 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   if (1 + c->tlas4.stack_need + 1 + blas_need > STACK4_LDS)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
                     " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
+  int r = upload_instances(c, inst_dev); if (r) return r;
   c->tlas_valid = true;
-  return upload_instances(c);
+  return RT_OK;
 }
 
 int rt_set_uniforms(rt_ctx* c, const rt_uniforms* u) {
@@ -706,14 +821,15 @@ int rt_set_skybox(rt_ctx* c, const uint8_t* const faces[6], int w, int h) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!faces || w <= 0 || h <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad skybox arguments");
   for (int f = 0; f < 6; f++) if (!faces[f]) return fail(c, RT_ERR_INVALID_ARGUMENT, "skybox face is NULL");
-  { int q = quiesce(c); if (q) return q; }
+  { int q = quiesce_scene(c); if (q) return q; }
   HIP_TRY(c, hipSetDevice(c->device));
+  Scene* S = c->scene;
   const size_t face_bytes = (size_t)w * h * 4;
-  if (c->d_sky) { HIP_TRY(c, hipFree(c->d_sky)); c->d_sky = nullptr; }
-  HIP_TRY(c, hipMalloc((void**)&c->d_sky, 6 * face_bytes));
+  if (S->d_sky) { HIP_TRY(c, hipFree(S->d_sky)); S->d_sky = nullptr; }
+  HIP_TRY(c, hipMalloc((void**)&S->d_sky, 6 * face_bytes));
   for (int f = 0; f < 6; f++)
-    HIP_TRY(c, hipMemcpy((uint8_t*)c->d_sky + f * face_bytes, faces[f], face_bytes, hipMemcpyHostToDevice));
-  c->sky_w = w; c->sky_h = h;
+    HIP_TRY(c, hipMemcpy((uint8_t*)S->d_sky + f * face_bytes, faces[f], face_bytes, hipMemcpyHostToDevice));
+  S->sky_w = w; S->sky_h = h;
   return RT_OK;
 }
 
@@ -730,26 +846,30 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   std::string k(name);
   if (k == "trace_variant") {
     if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0, 1 or 2");
+    { int q = quiesce_scene(c); if (q) return q; }
+    Scene* S = c->scene;
     const int before = c->cfg.variant;
-    c->cfg.variant = value;
-    if (value == 2 && before != 2 && c->blas_linked) {
-      // the 4-ary records are derived from the linked BVH2 on demand
-      c->blas_linked = false;
-      if (c->tlas_valid) { std::vector<rt_instance> keep = c->h_inst; c->tlas_valid = false; return rt_set_instances(c, keep.data(), (int)keep.size(), 0); }
-    }
+    for (rt_ctx* m : S->members) m->cfg.variant = value;   // the linked arrays are per scene: every slot walks the same ones
+    bool relink = (value == 2 && before != 2 && S->blas_linked);   // the 4-ary records are derived from the linked BVH2 on demand
     if (value == 1) {
       // the quad kernel walks the BVH4 that only the host builder produces: rebuild device-built meshes on the host
-      bool rebuilt = false;
-      for (size_t mi = 0; mi < c->meshes.size(); mi++) {
-        Mesh& m = c->meshes[mi];
+      for (size_t mi = 0; mi < S->meshes.size(); mi++) {
+        Mesh& m = S->meshes[mi];
         if (!m.built || !m.gpu_built) continue;
-        build_blas(c->h_verts.data() + m.range.first_float, c->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
+        build_blas(S->h_verts.data() + m.range.first_float, S->h_idx.data() + m.range.first_index, m.range.prim_count, m.bvh, m.tris);
         collapse_bvh4(m.bvh, true, false, m.bvh4);
-        m.bounds = m.bvh.bounds; m.gpu_built = false; rebuilt = true;
+        m.bounds = m.bvh.bounds; m.gpu_built = false; relink = true;
       }
-      if (rebuilt) {
-        c->blas_linked = false;
-        if (c->tlas_valid) { std::vector<rt_instance> keep = c->h_inst; c->tlas_valid = false; return rt_set_instances(c, keep.data(), (int)keep.size(), 0); }
+    }
+    if (relink) {
+      S->blas_linked = false;
+      // slots that had a TLAS get it back (same instances, fresh build) once the arrays are linked again
+      for (rt_ctx* m : S->members) {
+        if (!m->tlas_valid) continue;
+        std::vector<rt_instance> keep = m->h_inst;
+        m->tlas_valid = false;
+        int r = rt_set_instances(m, keep.data(), (int)keep.size(), 0);
+        if (r) { if (m != c) c->error = m->error; return r; }
       }
     }
     return RT_OK;
@@ -766,7 +886,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
-  if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); c->blas_builder = value; return RT_OK; }
+  if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); for (rt_ctx* m : c->scene->members) m->blas_builder = value; return RT_OK; }
   if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
   if (k == "trace_min_blocks") { if (value < 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_min_blocks must be >= 8"); c->cfg.min_blocks = value; return RT_OK; }
   if (k == "shade_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "shade_blocks_per_cu must be 1..16"); c->cfg.shade_blocks = c->n_cu * value; return RT_OK; }

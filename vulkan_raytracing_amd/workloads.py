@@ -14,14 +14,14 @@ from .api import INSTANCE_DTYPE
 IDENTITY12 = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
 
 
-def ring_instances(n_inst, radius, ring_mesh=1, center_mesh=0):
+def ring_instances(n_inst, radius, ring_mesh=1, center_mesh=0, phase=0.0, center_transform=None):
     """cfg5: n instances of the orbiting mesh's BLAS on a ring about the origin (generalises M1 = T(0,0,5) of
     src/main.cpp:1805-1808), all with customIndex 1 (src/shader.rchit:52 selects the orbiting mesh's buffer range with
     it), plus the center mesh as instance 0 / customIndex 0."""
     inst = np.zeros(n_inst + 1, INSTANCE_DTYPE)
-    inst[0] = host.make_instance(IDENTITY12, 0, center_mesh)
+    inst[0] = host.make_instance(IDENTITY12 if center_transform is None else center_transform, 0, center_mesh)
     for k in range(n_inst):
-        a = 2.0 * np.pi * k / n_inst
+        a = 2.0 * np.pi * k / n_inst + phase
         c, s = np.float32(np.cos(a)), np.float32(np.sin(a))
         # R_y(a) * T(0,0,radius): rotation, then the translated offset
         t = np.array([c, 0, s, s * radius, 0, 1, 0, 0, -s, 0, c, c * radius], np.float32)
@@ -44,6 +44,7 @@ class Workload:
         self.sky_dir, self.width, self.height, self.mesh_label, self.note = sky_dir, width, height, mesh_label, note
         self._geom = None
         self._sky = None
+        self._anim = None
 
     @property
     def geometry(self):
@@ -56,6 +57,23 @@ class Workload:
         if self._sky is None and self.sky_dir:
             self._sky = host.load_skybox(self.sky_dir)
         return self._sky
+
+    def animate(self, time_param):
+        """Instance records of the next animated frame (src/main.cpp:2836-2851): M0 accumulates a tiny spin, the orbiting
+        mesh circles the centre at angle pi * timeParam — for cfg5 the whole ring does.  Same instance count as
+        `instances`, so rt_set_instances(update=1) applies."""
+        if self._anim is None:
+            self._anim = host.SceneAnimation()
+        self._anim.animate(float(time_param))
+        if len(self.instances) == 2:
+            return self._anim.instances((0, 1))
+        if len(self.instances) == 1:
+            t = self._anim.transforms()
+            inst = self.instances.copy()
+            inst[0] = host.make_instance(t[0], 0, 0)
+            return inst
+        t = self._anim.transforms()
+        return ring_instances(len(self.instances) - 1, 10.0, phase=float(np.pi * np.float32(time_param)), center_transform=t[0])
 
     def apply(self, target, sky=None):
         """target: RtContext, or any object with upload_geometry/set_instances/set_uniforms/set_skybox."""
