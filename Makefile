@@ -30,9 +30,14 @@ $(PKG)/librt_host.so: $(HOSTSRC) include/jpeg_decode.h include/rt_host.hpp inclu
 	g++ -O2 -std=c++17 -fPIC -shared -pthread -Wall -Iinclude -o $@ $(HOSTSRC)
 all: $(PKG)/librt_host.so
 
-# headless C++ host (counterpart of the reference's main()); links the product library only
-rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so include/rt_host.hpp
-	g++ -O2 -std=c++17 -pthread -Wall -Iinclude -o $@ host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp -L$(PKG) -lrt_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib
+# several GPUs of one node from one host process: C++ over the C ABI + RCCL called directly (include/rt_multi.h)
+$(PKG)/librt_multi.so: host/rt_multi.cpp include/rt_multi.h include/rt_api.h $(PKG)/librt_mi355x.so
+	$(HIPCC) -O2 -std=c++17 -fPIC -shared -Wall -Iinclude -I/opt/rocm/include -o $@ host/rt_multi.cpp -L$(PKG) -lrt_mi355x -L/opt/rocm/lib -lrccl -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+all: $(PKG)/librt_multi.so
+
+# headless C++ host (counterpart of the reference's main()); links the product libraries only
+rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so $(PKG)/librt_multi.so include/rt_host.hpp include/rt_multi.h
+	g++ -O2 -std=c++17 -pthread -Wall -Iinclude -o $@ host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp -L$(PKG) -lrt_multi -lrt_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 # kernel experiments: make exp EXP_NAME=<suffix> EXP_FLAGS="-DRT_EXP_..."  -> librt_mi355x_<suffix>.so (load with RT_LIB_VARIANT)
 exp:

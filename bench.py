@@ -284,6 +284,9 @@ def main():
     rig.sync()
     dt = rig.timed(args.steps, args.warmup, animate=args.animate)
     st = ctx.stats()        # counters of slot 0's last frame + MEAN event times over all its timed frames (every P-th step)
+    last_frame = None
+    if args.save_image and rank == 0 and rig.frames[(rig.counter - 1) % P] is not None:
+        last_frame = rig.frames[(rig.counter - 1) % P][:H].clone()   # the last frame of THE timed region
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     rays = torch.tensor([st.rays_primary, st.rays_secondary, st.rays_shadow], dtype=torch.float64, device=dev)
     if collective:
@@ -401,9 +404,8 @@ def main():
             except Exception as e:   # noqa: BLE001
                 roof["profile_note"] = "profiles/latest_profile.json unreadable: %r" % (e,)
         result["roofline"] = roof
-        last = (rig.counter - 1) % P
-        if args.save_image and rig.frames[last] is not None:
-            img = rig.frames[last][:H].cpu().numpy()
+        if last_frame is not None:
+            img = last_frame.cpu().numpy()
             if img.shape[-1] == 3:   # assembled multi-rank frame: RGB + the constant alpha
                 img = np.concatenate([img, np.ones(img.shape[:2] + (1,), np.float32)], axis=-1)
             with open(args.save_image, "wb") as fh:

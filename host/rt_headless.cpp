@@ -6,7 +6,9 @@
 //
 //   rt_headless [--width W] [--height H] [--frames N] [--dt SECONDS] [--bounce B] [--spp S]
 //               [--center OBJ] [--orbiting OBJ] [--center-type T] [--orbiting-type T]
-//               [--skybox DIR] [--out PREFIX] [--device D]
+//               [--skybox DIR] [--out PREFIX] [--device D] [--frames-in-flight P] [--rgba8]
+//               [--gpus N [--loopback]]   N GPUs of this node in one process: band sharding + RCCL gather (include/rt_multi.h);
+//                                         --loopback = N logical devices on GPU D, shards moved by device copies (no RCCL)
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -21,6 +23,7 @@
 #include "config.h"
 #include "jpeg_decode.h"
 #include "rt_host.hpp"
+#include "rt_multi.h"
 
 static void writePFM(const std::string& path, const std::vector<float>& rgba, int W, int H) {
   std::ofstream f(path, std::ios::binary);
@@ -49,8 +52,8 @@ static void writePPM(const std::string& path, const std::vector<float>& rgba, in
 
 int main(int argc, char** argv) {
   int W = 800, H = 600;  // the reference's window size (src/main.cpp:805)
-  int frames = 3, device = 0, inFlight = 1;
-  bool rgba8 = false;
+  int frames = 3, device = 0, inFlight = 1, gpus = 0;
+  bool rgba8 = false, loopback = false;
   float dt = 1.0f / 60.0f;
   std::string center = CENTER_MESH_OBJ_PATH, orbiting = ORBITING_MESH_OBJ_PATH, skyDir = SKYBOX_TEXTURE_DIR, out = "frame";
   rt_uniforms uniformStructure = rthost::defaultUniforms();
@@ -70,6 +73,8 @@ int main(int argc, char** argv) {
     else if (a == "--skybox") skyDir = next();
     else if (a == "--out") out = next();
     else if (a == "--device") device = atoi(next());
+    else if (a == "--gpus") gpus = atoi(next());
+    else if (a == "--loopback") loopback = true;
     else if (a == "--rgba8") rgba8 = true;   // frames come back in the 8-bit surface format the reference presents (src/main.cpp:1899); needs --frames-in-flight > 1
     else if (a == "--frames-in-flight") inFlight = std::max(1, atoi(next()));   // the reference: swapchain image count, src/main.cpp:1203
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -86,6 +91,87 @@ int main(int argc, char** argv) {
     rthost::SceneGeometry geometry = rthost::loadScene({center, orbiting});
     uniformStructure.orbiting_object_primitive_offset = geometry.orbitingObjectPrimitiveOffset();  // :1872
     uniformStructure.orbiting_object_vertex_offset = geometry.orbitingObjectVertexOffset();        // :1873
+
+    if (gpus > 0) {
+      // ---- several GPUs of one node, one process: include/rt_multi.h (band sharding + one RCCL gather per frame) -------------
+      auto check = [](int r, const char* fn, rtm_ctx* m) { if (r) throw std::runtime_error(std::string("RT multi exception: return code ") + std::to_string(r) + " (" + fn + "): " + rtm_last_error(m)); };
+      std::vector<int> ids(gpus);
+      for (int k = 0; k < gpus; k++) ids[k] = loopback ? device : k;
+      rtm_ctx* multi = nullptr;
+      check(rtm_create(&multi, gpus, ids.data(), inFlight, loopback ? RTM_LOOPBACK : 0), "rtm_create", nullptr);
+      check(rtm_upload_geometry(multi, geometry.vertexBuffer.data(), geometry.vertexBuffer.size(), geometry.indexBuffer.data(), geometry.indexBuffer.size(),
+                                geometry.ranges.data(), (int)geometry.ranges.size()), "rtm_upload_geometry", multi);
+      for (int m = 0; m < (int)geometry.ranges.size(); m++) check(rtm_build_blas(multi, m), "rtm_build_blas", multi);
+      const char* faces[6] = {"right", "left", "top", "bottom", "front", "back"};
+      std::vector<std::vector<uint8_t>> sky(6);
+      int sw = 0, sh = 0;
+      for (int f = 0; f < 6; f++) {
+        rtjpeg::Image img; std::string err;
+        if (!rtjpeg::decode_file((skyDir + "/" + faces[f] + ".jpg").c_str(), img, err)) throw std::runtime_error("skybox: " + err);
+        sky[f].swap(img.rgba); sw = img.w; sh = img.h;
+      }
+      const uint8_t* fp[6];
+      for (int f = 0; f < 6; f++) fp[f] = sky[f].data();
+      check(rtm_set_skybox(multi, fp, sw, sh), "rtm_set_skybox", multi);
+      if (rgba8) check(rtm_set_param(multi, "output_rgba8", 1), "rtm_set_param", multi);
+      rthost::SceneAnimation animation;
+      auto instances = [&]() {
+        std::vector<rt_instance> inst(2);
+        float t[12];
+        for (uint32_t i = 0; i < 2; i++) { rthost::glmToVulkan(animation.glmMatrices[i], t); inst[i] = rthost::createInstance(t, i, i); }
+        return inst;
+      };
+      for (int k = 0; k < inFlight; k++) { auto in = instances(); check(rtm_set_instances(multi, k, in.data(), 2, 0), "rtm_set_instances", multi); }
+      std::vector<char> pending(inFlight, 0);
+      uint64_t rays = 0; int collected = 0;
+      const void* px = nullptr;
+      float timeParam = 0.f;
+      auto collect = [&](int k) {
+        rt_stats st{};
+        check(rtm_trace_wait(multi, k, &px, &st), "rtm_trace_wait", multi);
+        rays += st.rays_primary + st.rays_secondary + st.rays_shadow; collected++; pending[k] = 0;
+      };
+      const int warm = std::min(frames, inFlight);
+      std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      for (int frame = 0; frame < frames + warm; frame++) {
+        const int k = frame % inFlight;
+        if (pending[k]) collect(k);
+        if (frame == warm) {
+          for (int j = 0; j < inFlight; j++) if (pending[j]) collect(j);
+          rays = 0; collected = 0; t0 = std::chrono::steady_clock::now();
+        }
+        timeParam += dt * 0.1f;
+        animation.animate(timeParam);
+        auto in = instances();
+        check(rtm_set_instances(multi, k, in.data(), 2, 1), "rtm_set_instances", multi);   // createTLAS(update = true), src/main.cpp:2853-2861
+        check(rtm_set_uniforms(multi, k, &uniformStructure), "rtm_set_uniforms", multi);    // copyData(uniform), src/main.cpp:2901-2903
+        check(rtm_trace_async(multi, k, W, H), "rtm_trace_async", multi);
+        pending[k] = 1;
+      }
+      const int last = (frames + warm - 1) % inFlight;
+      for (int j = 1; j <= inFlight; j++) { const int k = (last + j) % inFlight; if (pending[k]) collect(k); }
+      const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      printf("%d frames on %d %s, %d in flight: %dx%d  %.3f ms per frame  %.1f Mrays/s with every frame gathered on device %d and copied to host memory  mesh: %s\n",
+             collected, gpus, loopback ? "logical devices (loopback, one GPU)" : "GPUs (RCCL gather)", inFlight, W, H, ms / collected, rays / (ms * 1e3), ids[0], meshLabel.c_str());
+      if (rgba8) {
+        const unsigned char* b = static_cast<const unsigned char*>(px);
+        std::ofstream f(out + ".ppm", std::ios::binary);
+        f << "P6\n" << W << " " << H << "\n255\n";
+        std::vector<unsigned char> row((size_t)W * 3);
+        for (int y = 0; y < H; y++) {
+          for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = b[((size_t)y * W + x) * 4 + c];
+          f.write((const char*)row.data(), (std::streamsize)row.size());
+        }
+      } else {
+        const float* pf = static_cast<const float*>(px);
+        std::vector<float> image(pf, pf + (size_t)W * H * 4);
+        writePFM(out + ".pfm", image, W, H);
+        writePPM(out + ".ppm", image, W, H);
+      }
+      printf("wrote %s.%s\n", out.c_str(), rgba8 ? "ppm" : "pfm / .ppm");
+      rtm_destroy(multi);
+      return 0;
+    }
 
     rthost::Renderer renderer(device);
     renderer.uploadGeometry(geometry);  // + Bottom Level Acceleration Structures (src/main.cpp:1734-1799)

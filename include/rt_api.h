@@ -164,6 +164,13 @@ int rt_trace_shard(rt_ctx* ctx, int width, int height, int band_rows, int shard,
 int rt_trace_async(rt_ctx* ctx, int width, int height);
 int rt_trace_wait(rt_ctx* ctx, const void** pixels, rt_stats* stats);
 
+/* Root-side step of a multi-GPU frame (the analogue of the reference's vkCmdCopyImage into the presented image,
+ * src/main.cpp:2683-2686): after the gather, n_shards compact shards (as rt_trace_shard writes them, shard s at byte
+ * s * shard_stride_bytes) lie in d_gathered; this de-interleaves them into the width x height frame at d_frame (device
+ * pointers of ctx's GPU; pixel format = ctx's, RGBA32F or RGBA8), enqueued on hip_stream (NULL = the context's). */
+int rt_assemble_shards(rt_ctx* ctx, const void* d_gathered, int n_shards, size_t shard_stride_bytes, int width, int height,
+                       int band_rows, void* d_frame, size_t frame_capacity_bytes, void* hip_stream);
+
 /* number of rows rt_trace_shard writes for (height, band_rows, shard, n_shards) */
 int rt_shard_rows(int height, int band_rows, int shard, int n_shards);
 

@@ -5,6 +5,7 @@
 #ifndef RT_HOST_HPP
 #define RT_HOST_HPP
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -48,34 +49,30 @@ struct SceneGeometry {
   uint32_t orbitingObjectVertexOffset() const { return ranges.size() > 1 ? (uint32_t)ranges[1].first_float : 0; }
 };
 
-// src/main.cpp:1673-1682 (+ the documented rule for the reference's out-of-bounds read when an OBJ
-// has fewer `vn` than `v`: the vertex takes the vn of the LAST face corner that uses it).
-inline void interleaveVertices(const tinyobj::attrib_t& attrib, const std::vector<tinyobj::shape_t>& shapes, std::vector<float>& tmpBuffer) {
-  const std::vector<tinyobj::real_t>& vertices = attrib.vertices;
-  const std::vector<tinyobj::real_t>& normals = attrib.normals;
-  size_t vertexCount = vertices.size();
-  tmpBuffer.assign(2 * vertexCount, 0.0f);
-  const bool perVertexNormals = normals.size() == vertices.size();
-  for (size_t i = 0; i < vertexCount; i += 3) {
-    size_t offset = 2 * i, attribOffset = i;
-    tmpBuffer[offset] = vertices[attribOffset];
-    tmpBuffer[offset + 1] = vertices[attribOffset + 1];
-    tmpBuffer[offset + 2] = vertices[attribOffset + 2];
-    if (perVertexNormals) {
-      tmpBuffer[offset + 3] = normals[attribOffset];
-      tmpBuffer[offset + 4] = normals[attribOffset + 1];
-      tmpBuffer[offset + 5] = normals[attribOffset + 2];
+// The vertex buffer layout of src/main.cpp:1673-1682: six floats per OBJ vertex, position then the normal found at the
+// SAME index in attrib.normals (the reference ignores normal_index).  Written as a gather per vertex record.  When the file
+// has FEWER `vn` than `v` the reference reads past the normal array (undefined behaviour, e.g. cube_scene.obj: 18 vn for
+// 44 v); the defined rule used here instead: such a vertex takes the vn of the last face corner that references it.  With
+// at least as many normals as vertices the reference's in-bounds read is reproduced as is.
+inline void interleaveVertices(const tinyobj::attrib_t& attrib, const std::vector<tinyobj::shape_t>& shapes, std::vector<float>& out) {
+  const std::vector<tinyobj::real_t>& pos = attrib.vertices;
+  const std::vector<tinyobj::real_t>& nrm = attrib.normals;
+  const size_t nVerts = pos.size() / 3;
+  const bool normalsCoverVertices = nrm.size() >= pos.size();
+  out.assign(6 * nVerts, 0.0f);
+  for (size_t v = 0; v < nVerts; v++) {
+    float* rec = &out[6 * v];
+    std::copy(pos.begin() + 3 * v, pos.begin() + 3 * v + 3, rec);
+    if (normalsCoverVertices) std::copy(nrm.begin() + 3 * v, nrm.begin() + 3 * v + 3, rec + 3);
+  }
+  if (normalsCoverVertices) return;
+  for (const tinyobj::shape_t& shape : shapes)
+    for (const tinyobj::index_t& corner : shape.mesh.indices) {
+      if (corner.normal_index < 0 || corner.vertex_index < 0) continue;
+      const size_t v = (size_t)corner.vertex_index, n = (size_t)corner.normal_index;
+      if (3 * n + 2 >= nrm.size() || v >= nVerts) continue;
+      std::copy(nrm.begin() + 3 * n, nrm.begin() + 3 * n + 3, &out[6 * v + 3]);
     }
-  }
-  if (!perVertexNormals) {
-    for (const tinyobj::shape_t& shape : shapes)
-      for (const tinyobj::index_t& index : shape.mesh.indices) {
-        if (index.normal_index < 0 || index.vertex_index < 0) continue;
-        size_t o = 6 * (size_t)index.vertex_index, n = 3 * (size_t)index.normal_index;
-        if (n + 2 >= normals.size() || o + 5 >= tmpBuffer.size()) continue;
-        tmpBuffer[o + 3] = normals[n]; tmpBuffer[o + 4] = normals[n + 1]; tmpBuffer[o + 5] = normals[n + 2];
-      }
-  }
 }
 
 // src/main.cpp:1606-1729 for an arbitrary list of OBJ files ({CENTER, ORBITING} in the reference).

@@ -21,8 +21,9 @@ tiny_obj_loader.h on the same files (oracle/ref_ingest.cpp, tests/golden/make_in
 Deliberate, documented divergence: src/main.cpp:1679-1681 reads normals[3v..3v+2] out of bounds
 when an OBJ has fewer `vn` than `v` records (resources/cube_scene.obj: 18 vn, 44 v) — undefined
 behaviour in the reference.  Rule used here and by the product host code: when
-len(normals) != len(vertices), the per-vertex normal is the `vn` referenced by the LAST face
-corner (file order) that uses that vertex; vertices never referenced keep (0,0,0).
+len(normals) < len(vertices), the per-vertex normal is the `vn` referenced by the LAST face
+corner (file order) that uses that vertex; vertices never referenced keep (0,0,0).  With at least
+as many normals as vertices the reference's read is in bounds and is reproduced (normals[3v..3v+2]).
 """
 import math
 import struct
@@ -109,8 +110,8 @@ def interleave(obj):
     nv = len(obj.vertices) // 3
     out = np.zeros((nv, 6), np.float32)
     out[:, 0:3] = obj.vertices.reshape(nv, 3)
-    if len(obj.normals) == len(obj.vertices):
-        out[:, 3:6] = obj.normals.reshape(nv, 3)
+    if len(obj.normals) >= len(obj.vertices):
+        out[:, 3:6] = obj.normals[:3 * nv].reshape(nv, 3)
     else:  # documented divergence (reference behaviour is undefined here)
         nrm = obj.normals.reshape(-1, 3)
         for s in obj.shapes:

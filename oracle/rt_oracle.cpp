@@ -405,8 +405,40 @@ static void closest_hit_attributes(const Scene& s, const Hit& h, V3& P, V3& N, i
   objectIndex = in.custom_index;
 }
 
-// Cube-map lookup, VK_FILTER_LINEAR, CLAMP_TO_EDGE per face (seam filtering
-// across faces is NOT reproduced — differs from Vulkan only within half a texel of a face edge).
+// Cube-map lookup as the reference's sampler performs it (src/main.cpp:2393-2406: LINEAR mag/min on a CUBE view; the
+// address mode is irrelevant: Vulkan ignores wrap modes for cube images and, with linear filtering, takes footprint texels
+// that fall off the selected face from the NEIGHBOURING face — "cube map edge handling").  Face selection and (s,t) as in
+// SURVEY.md Appendix C.  A tap one texel beyond an edge is the texel of the adjacent face that touches the same edge
+// position; the one tap beyond a CORNER has no unique neighbour and is the average of the three texels around the corner,
+// i.e. of the other three taps of the footprint (the rule the Vulkan specification recommends; implementation-defined).
+// Faces must be square (a cube); a non-square layer set falls back to clamping per face.
+struct SkyTap { int layer, x, y; };
+// texel (x, y) of `layer`, x or y (not both) possibly -1 or W: the texel it denotes on the adjacent face.  Exact integer
+// arithmetic on doubled coordinates: S = 2x + 1 - W is the texel centre in units of 1/W on the face square [-W, W].
+static inline SkyTap sky_neighbour(int layer, int x, int y, int W) {
+  const int S = 2 * x + 1 - W, T = 2 * y + 1 - W;
+  int px, py, pz;   // the tap's centre on the (extended) face plane, scaled by W
+  switch (layer) {
+    case 0: px = W; py = -T; pz = -S; break;
+    case 1: px = -W; py = -T; pz = S; break;
+    case 2: px = S; py = W; pz = T; break;
+    case 3: px = S; py = -W; pz = -T; break;
+    case 4: px = S; py = -T; pz = W; break;
+    default: px = -S; py = -T; pz = -W; break;
+  }
+  const int ax = px < 0 ? -px : px, ay = py < 0 ? -py : py, az = pz < 0 ? -pz : pz;
+  int nl, sc, tc, ma;   // re-select the face: the out-of-range coordinate (W + 1) is the new major axis
+  if (az >= ax && az >= ay) { ma = az; if (pz >= 0) { nl = 4; sc = px; tc = -py; } else { nl = 5; sc = -px; tc = -py; } }
+  else if (ay >= ax)        { ma = ay; if (py >= 0) { nl = 2; sc = px; tc = pz; } else { nl = 3; sc = px; tc = -pz; } }
+  else                      { ma = ax; if (px >= 0) { nl = 0; sc = -pz; tc = -py; } else { nl = 1; sc = pz; tc = -py; } }
+  // floor(((sc / ma) + 1) / 2 * W), numerators are >= 0
+  SkyTap t;
+  t.layer = nl; t.x = ((sc + ma) * W) / (2 * ma); t.y = ((tc + ma) * W) / (2 * ma);
+  if (t.x > W - 1) t.x = W - 1;
+  if (t.y > W - 1) t.y = W - 1;
+  return t;
+}
+
 static V3 sample_sky(const Scene& s, V3 r) {
   if (s.sky_w == 0) return mk(0.f, 0.f, 0.f);
   float ax = fabsf(r.x), ay = fabsf(r.y), az = fabsf(r.z);
@@ -419,18 +451,32 @@ static V3 sample_sky(const Scene& s, V3 r) {
   float fu0 = floorf(u), fv0 = floorf(v);
   float wu = u - fu0, wv = v - fv0;
   int x0 = (int)fu0, y0 = (int)fv0, x1 = x0 + 1, y1 = y0 + 1;
+  const int W = s.sky_w, H = s.sky_h;
   auto cl = [](int a, int n) { return a < 0 ? 0 : (a >= n ? n - 1 : a); };
-  x0 = cl(x0, s.sky_w); x1 = cl(x1, s.sky_w); y0 = cl(y0, s.sky_h); y1 = cl(y1, s.sky_h);
-  const uint8_t* base = s.sky.data() + (size_t)layer * s.sky_w * s.sky_h * 4;
-  const uint8_t* c00 = base + ((size_t)y0 * s.sky_w + x0) * 4;
-  const uint8_t* c10 = base + ((size_t)y0 * s.sky_w + x1) * 4;
-  const uint8_t* c01 = base + ((size_t)y1 * s.sky_w + x0) * 4;
-  const uint8_t* c11 = base + ((size_t)y1 * s.sky_w + x1) * 4;
+  // guard against a direction exactly on the far edge (fs == 1 -> x0 == W - 1 is the largest value floor can give; keep taps within one texel of the face)
+  x0 = x0 < -1 ? -1 : (x0 > W - 1 ? W - 1 : x0); x1 = x0 + 1;
+  y0 = y0 < -1 ? -1 : (y0 > H - 1 ? H - 1 : y0); y1 = y0 + 1;
+  const int xs[4] = {x0, x1, x0, x1}, ys[4] = {y0, y0, y1, y1};   // c00, c10, c01, c11
+  float tap[4][3];
+  int corner = -1;
+  for (int k = 0; k < 4; k++) {
+    const bool ox = xs[k] < 0 || xs[k] >= W, oy = ys[k] < 0 || ys[k] >= H;
+    SkyTap t{layer, xs[k], ys[k]};
+    if (W != H) { t.x = cl(t.x, W); t.y = cl(t.y, H); }            // not a cube: per-face clamp
+    else if (ox && oy) { corner = k; continue; }
+    else if (ox || oy) t = sky_neighbour(layer, xs[k], ys[k], W);
+    const uint8_t* c = s.sky.data() + (((size_t)t.layer * H + t.y) * W + t.x) * 4;
+    for (int ch = 0; ch < 3; ch++) tap[k][ch] = (float)c[ch];
+  }
+  if (corner >= 0) {   // the three texels that meet at the cube corner, in footprint order
+    const int a = (corner + 1) & 3, b = (corner + 2) & 3, c = (corner + 3) & 3;
+    for (int ch = 0; ch < 3; ch++) tap[corner][ch] = ((tap[a][ch] + tap[b][ch]) + tap[c][ch]) / 3.0f;
+  }
   float out[3];
   float iu = 1.0f - wu, iv = 1.0f - wv;
   for (int k = 0; k < 3; k++) {
-    float a = fmaf((float)c10[k], wu, (float)c00[k] * iu);
-    float b = fmaf((float)c11[k], wu, (float)c01[k] * iu);
+    float a = fmaf(tap[1][k], wu, tap[0][k] * iu);
+    float b = fmaf(tap[3][k], wu, tap[2][k] * iu);
     out[k] = fmaf(b, wv, a * iv) / 255.0f;  // R8G8B8A8_UNORM, no sRGB decode (src/main.cpp:2124)
   }
   return mk(out[0], out[1], out[2]);

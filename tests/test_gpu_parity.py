@@ -783,6 +783,15 @@ def test_frame_slots_share_one_scene(ctx):
     slots = []
     try:
         sp = scenes.two_object_scene(paths[0], paths[1], 1, 0, 3, 2, sky=scenes.synthetic_skybox(64), ctx=root)
+        sp.ctx = None                                    # from here on `sp` drives the oracle only
+
+        def oracle_frame(instances, max_bounce):
+            u = sp.uniforms.copy()
+            u[0]["max_bounce_count"] = max_bounce
+            sp.set_instances(instances)
+            sp.orc.set_uniforms(u.tobytes())
+            return sp.orc.render(W, H)[0]
+
         slots = [root] + [root.frame_slot() for _ in range(3)]
         anim = host.SceneAnimation()
         inst, want = [], []
@@ -793,9 +802,7 @@ def test_frame_slots_share_one_scene(ctx):
             u[0]["max_bounce_count"] = 1 + k            # per-slot uniform block
             c.set_instances(inst[k])
             c.set_uniforms(u)
-            sp.set_instances(inst[k]); sp.orc.set_uniforms(u.tobytes())
-            ref, _ = sp.orc.render(W, H)
-            want.append(ref)
+            want.append(oracle_frame(inst[k], 1 + k))
         for _ in range(2):                               # all four in flight at once, twice
             for c in slots:
                 c.trace_async(W, H)
@@ -809,8 +816,7 @@ def test_frame_slots_share_one_scene(ctx):
         moved = anim.instances((0, 1))
         slots[0].set_instances(moved, update=True)
         img0, _ = slots[0].trace(W, H)
-        sp.set_instances(moved); u0 = sp.uniforms.copy(); u0[0]["max_bounce_count"] = 1; sp.orc.set_uniforms(u0.tobytes())
-        check_image(img0, sp.orc.render(W, H)[0])
+        check_image(img0, oracle_frame(moved, 1))
         for k, c in enumerate(slots[1:], 1):
             img, _ = c.trace_wait()
             check_image(img, want[k])
@@ -820,15 +826,13 @@ def test_frame_slots_share_one_scene(ctx):
         slots[2].set_instances(moved, update=True)
         slots[2].trace_shard(W, H, H, 0, 1, buf.data_ptr(), buf.numel() * 4, s2.cuda_stream)
         slots[2].synchronize()
-        sp.set_instances(moved); u2 = sp.uniforms.copy(); u2[0]["max_bounce_count"] = 3; sp.orc.set_uniforms(u2.tobytes())
-        check_image(buf.cpu().numpy(), sp.orc.render(W, H)[0])
+        check_image(buf.cpu().numpy(), oracle_frame(moved, 3))
         # the cube map is shared: replacing it through the root changes what every slot samples
         sky2 = scenes.synthetic_skybox(32, seed=99)
         root.set_skybox(sky2)
         sp.orc.set_skybox(sky2)
         img, _ = slots[3].trace(W, H)
-        sp.set_instances(inst[3]); u3 = sp.uniforms.copy(); u3[0]["max_bounce_count"] = 4; sp.orc.set_uniforms(u3.tobytes())
-        check_image(img, sp.orc.render(W, H)[0])
+        check_image(img, oracle_frame(inst[3], 4))
         # scene-building on any member: every slot has to set its instances again
         slots[1].upload_geometry(sp.geom.verts, sp.geom.idx, sp.geom.ranges)
         for c in slots:
@@ -837,10 +841,70 @@ def test_frame_slots_share_one_scene(ctx):
             assert e.value.code == 2
         slots[3].set_instances(inst[3])
         img, _ = slots[3].trace(W, H)
-        check_image(img, sp.orc.render(W, H)[0])
+        check_image(img, oracle_frame(inst[3], 4))
         with pytest.raises(RtError):
             [root.frame_slot() for _ in range(16)]       # at most 16 contexts per scene
     finally:
         for c in reversed(slots[1:]):
             c.close()
         root.close()
+
+
+def test_headless_multi_gpu_host_rccl_and_logical_shards(tmp_path):
+    """host/rt_headless --gpus N (librt_multi.so: one C++ process, band sharding, ONE gather per frame, de-interleave on the
+    root) against the single-context path of the same program: (a) N = 4 LOGICAL devices on this one GPU with the shards
+    moved by device copies (--loopback), (b) N = 1 through real RCCL (ncclCommInitAll + ncclGather on the frame's stream).
+    Same animated frame sequence, two frames in flight everywhere: the last frame must be identical bit for bit, in RGBA32F
+    and in the 8-bit surface format."""
+    import importlib.util
+    import subprocess
+    exe = os.path.join(scenes.ROOT, "rt_headless")
+    spec = importlib.util.spec_from_file_location("image_diff", os.path.join(scenes.ROOT, "tools", "image_diff.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    common = ["--width", "328", "--height", "203", "--frames", "5", "--dt", "0.5", "--bounce", "3", "--spp", "2", "--frames-in-flight", "2",
+              "--center", os.path.join(RES, "teapot.obj"), "--orbiting", os.path.join(RES, "cube.obj"), "--skybox", os.path.join(RES, "skybox_texture_test")]
+    outs = {}
+    for name, extra in (("single", []), ("loop4", ["--gpus", "4", "--loopback"]), ("rccl1", ["--gpus", "1"]), ("loop3", ["--gpus", "3", "--loopback"])):
+        out = str(tmp_path / name)
+        r = subprocess.run([exe] + common + extra + ["--out", out], cwd=scenes.ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, name + ": " + r.stdout[-800:] + r.stderr[-1500:]
+        assert "Mrays/s" in r.stdout
+        outs[name] = mod.read_image(out + ".pfm")
+    assert outs["single"].shape == (203, 328, 3) and np.isfinite(outs["single"]).all() and outs["single"].std() > 0.01
+    for name in ("loop4", "rccl1", "loop3"):
+        assert np.array_equal(outs[name], outs["single"]), name
+    pp = {}
+    for name, extra in (("single8", ["--rgba8"]), ("loop4_8", ["--gpus", "4", "--loopback", "--rgba8"])):
+        out = str(tmp_path / name)
+        r = subprocess.run([exe] + common + extra + ["--out", out], cwd=scenes.ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, name + ": " + r.stdout[-800:] + r.stderr[-1500:]
+        pp[name] = open(out + ".ppm", "rb").read()
+    assert pp["single8"] == pp["loop4_8"]
+
+
+def test_cube_seams_and_corners_on_the_gpu(ctx):
+    """Frames whose sky lookups straddle cube edges and a cube corner: an 8x8-texel cube map (half a texel is several degrees
+    wide) seen by a camera turned towards the +X/+Z/+Y corner.  sample_sky's neighbour-face taps and corner rule against
+    the oracle's, which tests/test_oracle.py checks against an independent float64 sampler and for continuity."""
+    rng = np.random.default_rng(17)
+    faces = []
+    for f in range(6):
+        img = np.zeros((8, 8, 4), np.uint8)
+        img[..., :3] = rng.integers(0, 256, (8, 8, 3))
+        img[..., 3] = 255
+        faces.append(img)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 2, 2, sky=faces, ctx=ctx)
+    W, H = 320, 200
+    seen = 0
+    for yaw, pitch in ((0.0, 0.0), (np.pi / 4, 0.0), (np.pi / 4, 0.6155), (-2.2, -0.62), (3.0, 1.2)):
+        cam = host.Camera((0.0, 0.0, 20.0))
+        cam.process_mouse_movement(float(yaw), float(pitch))
+        u = sp.uniforms.copy()
+        cam.to_uniforms(u)
+        sp.set_uniforms(u)
+        gpu, st = ctx.trace(W, H)
+        ref, rc = sp.orc.render(W, H)
+        check_image(gpu, ref)
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+        seen += 1
+    assert seen == 5

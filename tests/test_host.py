@@ -29,6 +29,31 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.rt_shard_rows(1080, 8, 0, 8) == tiling.shard_rows(1080, 8, 0, 8)
 
 
+def test_multi_gpu_library_exports_every_declared_symbol():
+    """librt_multi.so (host/rt_multi.cpp: one process, several GPUs, RCCL called directly) loads here and exports exactly
+    what include/rt_multi.h declares; without a GPU rtm_create fails loudly."""
+    hdr = open(os.path.join(ROOT, "include", "rt_multi.h")).read()
+    declared = set(re.findall(r"^\s*(?:int|void|const char\*)\s+(rtm_[a-z_0-9]+)\s*\(", hdr, re.M))
+    assert declared == {"rtm_create", "rtm_destroy", "rtm_upload_geometry", "rtm_build_blas", "rtm_set_skybox", "rtm_set_param", "rtm_set_instances",
+                        "rtm_set_uniforms", "rtm_trace_async", "rtm_trace_wait", "rtm_device_count", "rtm_last_error"}
+    so = os.path.join(ROOT, "vulkan_raytracing_amd", "librt_multi.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", ROOT, "vulkan_raytracing_amd/librt_multi.so"], stdout=subprocess.DEVNULL)
+    api.lib()                                   # librt_mi355x.so first (same search order as a host program's DT_NEEDED)
+    L = ctypes.CDLL(so)
+    for name in declared:
+        assert hasattr(L, name), name
+    import torch
+    if not torch.cuda.is_available():
+        h = ctypes.c_void_p()
+        ids = (ctypes.c_int * 1)(0)
+        L.rtm_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.c_int]
+        L.rtm_last_error.restype = ctypes.c_char_p
+        L.rtm_last_error.argtypes = [ctypes.c_void_p]
+        assert L.rtm_create(ctypes.byref(h), 1, ids, 2, 0) in (3, 5) and not h.value
+        assert b"no HIP device" in L.rtm_last_error(None) or b"HIP" in L.rtm_last_error(None)
+
+
 def test_no_gpu_means_loud_failure():
     """Without a HIP device the product refuses to run (no CPU fallback)."""
     import torch
@@ -93,6 +118,18 @@ def test_obj_loader_polygons_and_indices(tmp_path):
         host.SceneGeometry([str(q)])
     with pytest.raises(RuntimeError):
         host.SceneGeometry([str(tmp_path / "missing.obj")])
+
+
+def test_more_normals_than_vertices_reads_normals_at_the_vertex_index(tmp_path):
+    """src/main.cpp:1679-1681 reads normals[3v..3v+2] whatever the faces say.  With MORE `vn` than `v` that read is in bounds
+    and must be reproduced as is (the 'last face corner' rule is only for the undefined FEWER-vn case)."""
+    p = tmp_path / "m.obj"
+    p.write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nvn 1 0 0\nvn 0 1 0\nvn 0 0 1\nvn 0 0 -1\nvn 0.6 0.8 0\nf 1//5 2//4 3//4\n")
+    s = host.SceneGeometry([str(p)])
+    v = s.verts.reshape(-1, 6)
+    assert np.array_equal(v[:, 3:6], np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float32))
+    obj = ingest.parse_obj(str(p))
+    assert np.array_equal(ingest.interleave(obj), s.verts)
 
 
 def test_jpeg_decoder_matches_reference_decoder_golden(resources):

@@ -183,6 +183,118 @@ def test_bilinear_cube_filter_matches_float64():
         assert np.allclose(c, ref[:3], atol=2e-4)
 
 
+def _smooth_cube(size):
+    """cube map whose texels sample one smooth function of the direction (so that correct filtering is continuous everywhere)"""
+    faces = []
+    c = (np.arange(size) + 0.5) / size * 2.0 - 1.0
+    s, t = np.meshgrid(c, c)
+    one = np.ones_like(s)
+    dirs = [(one, -t, -s), (-one, -t, s), (s, one, t), (s, -one, -t), (s, -t, one), (-s, -t, -one)]   # Appendix C, inverted
+    for (x, y, z) in dirs:
+        n = np.sqrt(x * x + y * y + z * z)
+        x, y, z = x / n, y / n, z / n
+        img = np.zeros((size, size, 4), np.uint8)
+        img[..., 0] = np.round(127.5 + 127.5 * np.sin(3.0 * x + 1.0) * np.cos(2.0 * y - 0.5))
+        img[..., 1] = np.round(127.5 + 127.5 * np.sin(2.5 * z + 0.3) * np.cos(3.0 * x + y))
+        img[..., 2] = np.round(127.5 + 127.5 * np.sin(4.0 * y + 2.0 * z))
+        img[..., 3] = 255
+        faces.append(img)
+    return faces
+
+
+def _edge_directions(n_along, eps):
+    """pairs of directions straddling each of the 12 cube edges (and, with |w| -> 1, approaching the 8 corners)"""
+    pairs = []
+    for a in range(3):                       # the two axes that are tied along an edge: (a, b); the third runs along it
+        for b in range(a + 1, 3):
+            c = 3 - a - b
+            for sa in (-1.0, 1.0):
+                for sb in (-1.0, 1.0):
+                    for w in np.linspace(-0.97, 0.97, n_along):
+                        lo, hi = np.zeros(3), np.zeros(3)
+                        lo[a], lo[b], lo[c] = sa * (1.0 + eps), sb * 1.0, w      # |a| major
+                        hi[a], hi[b], hi[c] = sa * 1.0, sb * (1.0 + eps), w      # |b| major
+                        pairs.append((lo, hi))
+    return pairs
+
+
+def test_cube_filtering_is_seamless_across_all_twelve_edges():
+    """VK_FILTER_LINEAR on a cube view takes footprint texels that fall off the selected face from the neighbouring face
+    (src/main.cpp:2393-2406; Vulkan 'cube map edge handling'): the filtered colour is continuous across every edge.  A
+    per-face clamp (round 1) jumps there by up to half a texel's gradient (~0.05 on this 16^2 map)."""
+    S = oracle.OracleScene()
+    S.set_skybox(_smooth_cube(16))
+    worst = 0.0
+    for lo, hi in _edge_directions(25, 1e-5):
+        worst = max(worst, float(np.abs(S.sample_sky(lo.astype(np.float32)) - S.sample_sky(hi.astype(np.float32))).max()))
+    assert worst < 2e-3, worst
+
+
+def test_cube_edge_and_corner_taps_match_an_independent_float64_sampler():
+    """Directions within half a texel of every edge and corner against a float64 sampler written differently: every tap is
+    located by projecting its texel CENTRE (on the extended face plane) back onto the cube and taking the nearest texel
+    there; the tap beyond a corner is the mean of the other three."""
+    size = 8
+    faces = _smooth_cube(size)
+    rng = np.random.default_rng(5)
+    for f in faces:
+        f[..., :3] = rng.integers(0, 256, f[..., :3].shape)      # uncorrelated texels: a wrong neighbour cannot hide
+    S = oracle.OracleScene()
+    S.set_skybox(faces)
+    tex = np.stack(faces).astype(np.float64)[..., :3]
+
+    def face_of(r):
+        ax = np.abs(r)
+        if ax[2] >= ax[0] and ax[2] >= ax[1]:
+            return (4, r[0], -r[1], ax[2]) if r[2] >= 0 else (5, -r[0], -r[1], ax[2])
+        if ax[1] >= ax[0]:
+            return (2, r[0], r[2], ax[1]) if r[1] >= 0 else (3, r[0], -r[2], ax[1])
+        return (0, -r[2], -r[1], ax[0]) if r[0] >= 0 else (1, r[2], -r[1], ax[0])
+
+    def point_on(layer, s, t):
+        return np.array({0: (1, -t, -s), 1: (-1, -t, s), 2: (s, 1, t), 3: (s, -1, -t), 4: (s, -t, 1), 5: (-s, -t, -1)}[layer], np.float64)
+
+    def ref(r):
+        layer, sc, tc, ma = face_of(np.asarray(r, np.float64))
+        u, v = 0.5 * (sc / ma + 1.0) * size - 0.5, 0.5 * (tc / ma + 1.0) * size - 0.5
+        x0, y0 = int(np.floor(u)), int(np.floor(v))
+        wu, wv = u - x0, v - y0
+        taps, missing = {}, None
+        for k, (x, y) in enumerate(((x0, y0), (x0 + 1, y0), (x0, y0 + 1), (x0 + 1, y0 + 1))):
+            ox, oy = not (0 <= x < size), not (0 <= y < size)
+            if ox and oy:
+                missing = k
+                continue
+            if ox or oy:
+                l2, s2, t2, m2 = face_of(point_on(layer, (2 * x + 1) / size - 1.0, (2 * y + 1) / size - 1.0))
+                xx = min(size - 1, int(np.floor(0.5 * (s2 / m2 + 1.0) * size)))
+                yy = min(size - 1, int(np.floor(0.5 * (t2 / m2 + 1.0) * size)))
+                taps[k] = tex[l2, yy, xx]
+            else:
+                taps[k] = tex[layer, y, x]
+        if missing is not None:
+            taps[missing] = sum(taps.values()) / 3.0
+        a = taps[0] * (1 - wu) + taps[1] * wu
+        b = taps[2] * (1 - wu) + taps[3] * wu
+        return (a * (1 - wv) + b * wv) / 255.0
+
+    n_corner = 0
+    dirs = [p for pair in _edge_directions(9, 0.4 / size) for p in pair]
+    for sx in (-1, 1):
+        for sy in (-1, 1):
+            for sz in (-1, 1):
+                for _ in range(12):
+                    dirs.append(np.array([sx, sy, sz], np.float64) * (1.0 - rng.uniform(0, 0.9 / size, 3)))
+    for r in dirs:
+        got = S.sample_sky(np.asarray(r, np.float32))
+        want = ref(np.asarray(r, np.float32).astype(np.float64))
+        assert np.abs(got - want).max() < 2e-6, (r, got, want)
+        layer, sc, tc, ma = face_of(np.asarray(r, np.float64))
+        u, v = 0.5 * (sc / ma + 1.0) * size - 0.5, 0.5 * (tc / ma + 1.0) * size - 0.5
+        n_corner += (u < 0 or u > size - 1) and (v < 0 or v > size - 1)
+    assert n_corner >= 40       # footprints that straddle three faces were exercised
+
+
 def test_invert_affine_and_pow100():
     L = oracle.lib()
     rng = np.random.default_rng(4)

@@ -34,7 +34,7 @@ class RtStats(C.Structure):
 
 
 EXPORTS = ["rt_create", "rt_create_frame_slot", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
-           "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
+           "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_assemble_shards", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
            "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_debug_sizing", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
 _LIB = None
@@ -59,6 +59,7 @@ def lib():
         L.rt_trace_async.argtypes = [vp, C.c_int, C.c_int]
         L.rt_trace_wait.argtypes = [vp, C.POINTER(vp), C.POINTER(RtStats)]
         L.rt_trace_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        L.rt_assemble_shards.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.rt_shard_rows.argtypes = [C.c_int] * 4
         L.rt_synchronize.argtypes = [vp]
         L.rt_get_stats.argtypes = [vp, C.POINTER(RtStats)]
@@ -184,6 +185,10 @@ class RtContext:
     def trace_shard(self, W, H, band_rows, shard, n_shards, d_out_ptr, capacity_bytes, stream_ptr=None):
         self._chk(self.L.rt_trace_shard(self.h, W, H, band_rows, shard, n_shards, C.c_void_p(d_out_ptr), capacity_bytes,
                                         C.c_void_p(stream_ptr) if stream_ptr else None), "rt_trace_shard")
+
+    def assemble_shards(self, d_gathered_ptr, n_shards, shard_stride_bytes, W, H, band_rows, d_frame_ptr, capacity_bytes, stream_ptr=None):
+        self._chk(self.L.rt_assemble_shards(self.h, C.c_void_p(d_gathered_ptr), n_shards, shard_stride_bytes, W, H, band_rows, C.c_void_p(d_frame_ptr),
+                                            capacity_bytes, C.c_void_p(stream_ptr) if stream_ptr else None), "rt_assemble_shards")
 
     def synchronize(self):
         self._chk(self.L.rt_synchronize(self.h), "rt_synchronize")

@@ -196,7 +196,44 @@ __device__ __forceinline__ float div255(float x) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Cube-map lookup (LINEAR, CLAMP_TO_EDGE per face, RGBA8 UNORM) — same arithmetic as oracle sample_sky.
+// Cube-map lookup (LINEAR on a cube view, RGBA8 UNORM, src/main.cpp:2393-2406) — same arithmetic as oracle sample_sky.
+// Footprint texels that fall off the selected face come from the neighbouring face (Vulkan cube map edge handling); the
+// tap beyond a corner is the mean of the other three.  Only ~1/W of all lookups touch an edge, so that path lives in its
+// own function and the common path stays four plain loads.
+struct SkyTap { int layer, x, y; };
+__device__ __forceinline__ SkyTap sky_neighbour(int layer, int x, int y, int W) {
+  const int S = 2 * x + 1 - W, T = 2 * y + 1 - W;
+  int px, py, pz;
+  switch (layer) {
+    case 0: px = W; py = -T; pz = -S; break;
+    case 1: px = -W; py = -T; pz = S; break;
+    case 2: px = S; py = W; pz = T; break;
+    case 3: px = S; py = -W; pz = -T; break;
+    case 4: px = S; py = -T; pz = W; break;
+    default: px = -S; py = -T; pz = -W; break;
+  }
+  const int ax = abs(px), ay = abs(py), az = abs(pz);
+  int nl, sc, tc, ma;
+  if (az >= ax && az >= ay) { ma = az; if (pz >= 0) { nl = 4; sc = px; tc = -py; } else { nl = 5; sc = -px; tc = -py; } }
+  else if (ay >= ax)        { ma = ay; if (py >= 0) { nl = 2; sc = px; tc = pz; } else { nl = 3; sc = px; tc = -pz; } }
+  else                      { ma = ax; if (px >= 0) { nl = 0; sc = -pz; tc = -py; } else { nl = 1; sc = pz; tc = -py; } }
+  SkyTap t;
+  t.layer = nl; t.x = min(((sc + ma) * W) / (2 * ma), W - 1); t.y = min(((tc + ma) * W) / (2 * ma), W - 1);
+  return t;
+}
+// texel index (in uchar4 units from the start of the cube map) of tap (x, y) of `layer`, either coordinate possibly one
+// texel beyond the face; SKY_CORNER when both are (no unique neighbour).  Out of line and returning one register: only
+// ~1/W of all lookups come here, and the common path must not pay registers or scratch for it.
+constexpr uint32_t SKY_CORNER = 0xFFFFFFFFu;
+__device__ __noinline__ uint32_t sky_tap_index(int layer, int x, int y, int W, int H) {
+  const bool ox = x < 0 || x >= W, oy = y < 0 || y >= H;
+  SkyTap t; t.layer = layer; t.x = x; t.y = y;
+  if (W != H) { t.x = max(0, min(x, W - 1)); t.y = max(0, min(y, H - 1)); }   // not a cube: per-face clamp
+  else if (ox && oy) return SKY_CORNER;
+  else if (ox || oy) t = sky_neighbour(layer, x, y, W);
+  return ((uint32_t)t.layer * (uint32_t)H + (uint32_t)t.y) * (uint32_t)W + (uint32_t)t.x;
+}
+
 __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
   if (sc.sky_w == 0) return mk3(0.f, 0.f, 0.f);
   const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
@@ -208,16 +245,31 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
   const float u = fs * (float)sc.sky_w - 0.5f, v = ft * (float)sc.sky_h - 0.5f;
   const float fu0 = __builtin_floorf(u), fv0 = __builtin_floorf(v);
   const float wu = u - fu0, wv = v - fv0;
-  int x0 = (int)fu0, y0 = (int)fv0, x1 = x0 + 1, y1 = y0 + 1;
-  x0 = max(0, min(x0, sc.sky_w - 1)); x1 = max(0, min(x1, sc.sky_w - 1));
-  y0 = max(0, min(y0, sc.sky_h - 1)); y1 = max(0, min(y1, sc.sky_h - 1));
-  const uchar4* base = sc.sky + (size_t)layer * sc.sky_w * sc.sky_h;
-  const uchar4 c00 = base[(size_t)y0 * sc.sky_w + x0], c10 = base[(size_t)y0 * sc.sky_w + x1];
-  const uchar4 c01 = base[(size_t)y1 * sc.sky_w + x0], c11 = base[(size_t)y1 * sc.sky_w + x1];
+  const int W = sc.sky_w, H = sc.sky_h;
+  int x0 = (int)fu0, y0 = (int)fv0;
+  x0 = max(-1, min(x0, W - 1)); y0 = max(-1, min(y0, H - 1));
+  uint32_t i00 = ((uint32_t)layer * (uint32_t)H + (uint32_t)y0) * (uint32_t)W + (uint32_t)x0, i10 = i00 + 1u, i01 = i00 + (uint32_t)W, i11 = i01 + 1u;
+  const bool edge = !(x0 >= 0 && x0 + 1 < W && y0 >= 0 && y0 + 1 < H);
+  if (edge) {
+    i00 = sky_tap_index(layer, x0, y0, W, H); i10 = sky_tap_index(layer, x0 + 1, y0, W, H);
+    i01 = sky_tap_index(layer, x0, y0 + 1, W, H); i11 = sky_tap_index(layer, x0 + 1, y0 + 1, W, H);
+  }
+  const uchar4 a = sc.sky[i00 == SKY_CORNER ? 0u : i00], b = sc.sky[i10 == SKY_CORNER ? 0u : i10];
+  const uchar4 c = sc.sky[i01 == SKY_CORNER ? 0u : i01], d = sc.sky[i11 == SKY_CORNER ? 0u : i11];
+  float c00x = (float)a.x, c00y = (float)a.y, c00z = (float)a.z, c10x = (float)b.x, c10y = (float)b.y, c10z = (float)b.z;
+  float c01x = (float)c.x, c01y = (float)c.y, c01z = (float)c.z, c11x = (float)d.x, c11y = (float)d.y, c11z = (float)d.z;
+  if (edge) {
+    // the tap beyond a cube corner = mean of the other three, summed in footprint order starting behind the corner tap
+    // (taps are numbered 00, 10, 01, 11; oracle: ((t[k+1] + t[k+2]) + t[k+3]) / 3)
+    if (i00 == SKY_CORNER) { c00x = ((c10x + c01x) + c11x) / 3.0f; c00y = ((c10y + c01y) + c11y) / 3.0f; c00z = ((c10z + c01z) + c11z) / 3.0f; }
+    if (i10 == SKY_CORNER) { c10x = ((c01x + c11x) + c00x) / 3.0f; c10y = ((c01y + c11y) + c00y) / 3.0f; c10z = ((c01z + c11z) + c00z) / 3.0f; }
+    if (i01 == SKY_CORNER) { c01x = ((c11x + c00x) + c10x) / 3.0f; c01y = ((c11y + c00y) + c10y) / 3.0f; c01z = ((c11z + c00z) + c10z) / 3.0f; }
+    if (i11 == SKY_CORNER) { c11x = ((c00x + c10x) + c01x) / 3.0f; c11y = ((c00y + c10y) + c01y) / 3.0f; c11z = ((c00z + c10z) + c01z) / 3.0f; }
+  }
   const float iu = 1.0f - wu, iv = 1.0f - wv;
-  float ra = __builtin_fmaf((float)c10.x, wu, (float)c00.x * iu), rb = __builtin_fmaf((float)c11.x, wu, (float)c01.x * iu);
-  float ga = __builtin_fmaf((float)c10.y, wu, (float)c00.y * iu), gb = __builtin_fmaf((float)c11.y, wu, (float)c01.y * iu);
-  float ba = __builtin_fmaf((float)c10.z, wu, (float)c00.z * iu), bb = __builtin_fmaf((float)c11.z, wu, (float)c01.z * iu);
+  float ra = __builtin_fmaf(c10x, wu, c00x * iu), rb = __builtin_fmaf(c11x, wu, c01x * iu);
+  float ga = __builtin_fmaf(c10y, wu, c00y * iu), gb = __builtin_fmaf(c11y, wu, c01y * iu);
+  float ba = __builtin_fmaf(c10z, wu, c00z * iu), bb = __builtin_fmaf(c11z, wu, c01z * iu);
   return mk3(div255(__builtin_fmaf(rb, wv, ra * iv)), div255(__builtin_fmaf(gb, wv, ga * iv)), div255(__builtin_fmaf(bb, wv, ba * iv)));
 }
 
@@ -1279,6 +1331,28 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s) {
   ShadeArgs a{sc, f, u, bounce};
   hipLaunchKernelGGL(k_shade, dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_assemble: the de-interleave step after the multi-GPU gather (the reference's image copy to the swapchain,
+// src/main.cpp:2683-2686, is the single-GPU analogue).  `gathered` holds n_shards compact shards back to back
+// (shard_stride units each: band after band of shard s = bands s, s + n, s + 2n, ...); row y of the frame is row
+// (y / band_rows / n_shards) * band_rows + y % band_rows of shard (y / band_rows) % n_shards.  One thread per 16-byte
+// (RGBA32F pixel) or 4-byte (RGBA8 pixel) unit: coalesced row copies, no arithmetic on the pixels.
+template <typename T>
+__global__ __launch_bounds__(256) void k_assemble(const T* __restrict__ gathered, T* __restrict__ out, uint32_t width, uint32_t height,
+                                                   uint32_t band_rows, uint32_t n_shards, size_t shard_stride) {
+  const uint32_t x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+  if (x >= width || y >= height) return;
+  const uint32_t band = y / band_rows, within = y - band * band_rows;
+  const uint32_t shard = band % n_shards, local = (band / n_shards) * band_rows + within;
+  out[(size_t)y * width + x] = gathered[(size_t)shard * shard_stride + (size_t)local * width + x];
+}
+
+void launch_assemble(const void* gathered, void* out, int width, int height, int band_rows, int n_shards, size_t shard_stride_px, bool rgba8, hipStream_t s) {
+  const dim3 g(((uint32_t)width + 255u) / 256u, (uint32_t)height), b(256);
+  if (rgba8) hipLaunchKernelGGL((k_assemble<uint32_t>), g, b, 0, s, (const uint32_t*)gathered, (uint32_t*)out, (uint32_t)width, (uint32_t)height, (uint32_t)band_rows, (uint32_t)n_shards, shard_stride_px);
+  else hipLaunchKernelGGL((k_assemble<float4>), g, b, 0, s, (const float4*)gathered, (float4*)out, (uint32_t)width, (uint32_t)height, (uint32_t)band_rows, (uint32_t)n_shards, shard_stride_px);
 }
 
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s) {

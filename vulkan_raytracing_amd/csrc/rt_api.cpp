@@ -996,6 +996,24 @@ int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shar
   return enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
 }
 
+// Root-side step of a multi-GPU frame: n_shards compact shards (as rt_trace_shard writes them, each padded to
+// shard_stride_bytes) lie back to back in d_gathered after the gather; this writes the width x height frame to d_frame on
+// hip_stream (NULL = the context's stream).  Pixel format = the context's ("output_rgba8").  Asynchronous.
+int rt_assemble_shards(rt_ctx* c, const void* d_gathered, int n_shards, size_t shard_stride_bytes, int W, int H, int band_rows,
+                       void* d_frame, size_t frame_capacity_bytes, void* hip_stream) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  const size_t bpp = c->out_rgba8 ? 4 : 16;
+  if (!d_gathered || !d_frame || n_shards <= 0 || W <= 0 || H <= 0 || band_rows <= 0 || shard_stride_bytes % bpp != 0)
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_assemble_shards arguments");
+  if ((size_t)W * H * bpp > frame_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame buffer too small");
+  for (int s = 0; s < n_shards; s++)
+    if ((size_t)rt_shard_rows(H, band_rows, s, n_shards) * W * bpp > shard_stride_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "shard stride smaller than a shard");
+  HIP_TRY(c, hipSetDevice(c->device));
+  launch_assemble(d_gathered, d_frame, W, H, band_rows, n_shards, shard_stride_bytes / bpp, c->out_rgba8, hip_stream ? (hipStream_t)hip_stream : c->stream);
+  HIP_TRY(c, hipGetLastError());
+  return RT_OK;
+}
+
 int rt_synchronize(rt_ctx* c) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   HIP_TRY(c, hipSetDevice(c->device));

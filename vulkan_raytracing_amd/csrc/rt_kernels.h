@@ -67,6 +67,8 @@ void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
 void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, uint32_t shard_cap,
                       int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s);
 
+// de-interleave n_shards gathered compact shards (shard_stride_px pixels apart) into the width x height frame
+void launch_assemble(const void* gathered, void* out, int width, int height, int band_rows, int n_shards, size_t shard_stride_px, bool rgba8, hipStream_t s);
 int trace_threads_per_block();
 // resident workgroups of k_tail per CU (occupancy query; <= 0 on failure)
 int tail_blocks_per_cu();
