@@ -138,6 +138,25 @@ int rt_build_blas(rt_ctx* ctx, int mesh);
  * context's stream and the next frame is ordered behind them (the reference blocks on a fence here, src/main.cpp:772-778). */
 int rt_set_instances(rt_ctx* ctx, const rt_instance* instances, int n, int update);
 
+/* ---- MTL materials and a per-instance type table -------------------------------------------------
+ * The reference's loader parses Kd/Ks/Ns/Ni/illum (include/tiny_obj_loader.h:565 GetMaterials) and its renderer ignores
+ * them: src/shader.rgen:51-55 hard-codes ka (.1,.3,.1), kd (.2,1,.2), ks .8, exponent 100, index of refraction 1.52, and
+ * src/shader.rgen:96 knows two object types ("Hardcoded as 2 objects", src/main.cpp:2425).  Both calls are optional:
+ * without them every frame is the reference's, bit for bit. */
+typedef struct rt_material {
+  float ka[3]; float ns;        /* Ka;  Ns = specular exponent, applied as an integer power (rounded, 0..1023) */
+  float kd[3]; float ni;        /* Kd;  Ni = index of refraction of a refractive surface */
+  float ks[3]; uint32_t type;   /* Ks;  0 diffuse, 1 mirror, 2 refractive, or RT_MATERIAL_TYPE_OF_INSTANCE */
+} rt_material;
+#define RT_MATERIAL_TYPE_OF_INSTANCE 0xFFFFFFFFu   /* the surface's type is its instance's (rt_set_instance_types / the uniform block) */
+/* table[prim_material[g]] shades triangle g of the shared index buffer, g = first_index / 3 + gl_PrimitiveID (one entry per
+ * triangle: n_prims = n_idx / 3).  Scene state, shared by all frame slots; n_materials == 0 removes the table.  With a table the
+ * diffuse branch evaluates Iamb*ka, kd, ks, pow(., Ns) and the refractive branch Ni from the hit triangle's material. */
+int rt_set_materials(rt_ctx* ctx, const rt_material* table, int n_materials, const uint32_t* prim_material, size_t n_prims);
+/* types[i] in {0,1,2} for instance i of this context's next rt_set_instances (and of the current ones, re-issued at once);
+ * n == 0 restores `objectIndex == 0 ? centerObjectType : orbitingObjectType` (src/shader.rgen:96). */
+int rt_set_instance_types(rt_ctx* ctx, const uint32_t* types, int n);
+
 /* Uniform buffer copyData (src/main.cpp:1887-1889, 2901-2903). */
 int rt_set_uniforms(rt_ctx* ctx, const rt_uniforms* u);
 

@@ -44,6 +44,12 @@ struct SceneGeometry {
   std::vector<uint32_t> indexBuffer;        // objects concatenated, object-local indices
   std::vector<uint32_t> primitiveCount;     // per object
   std::vector<rt_mesh_range> ranges;        // per object offsets
+  // SURVEY.md §8(f) n4 — what the reference's loader parses and its renderer drops (src/main.cpp:1644-1650 keeps only
+  // vertex_index): the MTL materials of every object and the material of every triangle.  materials[0] is the reference's
+  // hard-coded surface (src/shader.rgen:51-55) for faces without `usemtl`; rt_set_materials(materials, primMaterial) turns
+  // them on, nothing else reads them.
+  std::vector<rt_material> materials;
+  std::vector<uint32_t> primMaterial;       // one per triangle of indexBuffer
   // src/main.cpp:1872-1873
   uint32_t orbitingObjectPrimitiveOffset() const { return ranges.size() > 1 ? (uint32_t)(ranges[1].first_index / 3) : 0; }
   uint32_t orbitingObjectVertexOffset() const { return ranges.size() > 1 ? (uint32_t)ranges[1].first_float : 0; }
@@ -75,9 +81,28 @@ inline void interleaveVertices(const tinyobj::attrib_t& attrib, const std::vecto
     }
 }
 
+// The surface src/shader.rgen:51-55 hard-codes, as a material record.
+inline rt_material referenceMaterial() {
+  rt_material m{};
+  m.ka[0] = 0.1f; m.ka[1] = 0.3f; m.ka[2] = 0.1f; m.ns = 100.0f;
+  m.kd[0] = 0.2f; m.kd[1] = 1.0f; m.kd[2] = 0.2f; m.ni = 1.52f;
+  m.ks[0] = m.ks[1] = m.ks[2] = 0.8f; m.type = RT_MATERIAL_TYPE_OF_INSTANCE;
+  return m;
+}
+// MTL record -> rt_material.  illum 3 (reflection, ray traced) makes the surface a mirror, illum 4/6/7/9 (glass / refraction)
+// refractive; every other model leaves the type to the instance, as the reference's CENTER/ORBITING_MESH_TYPE do.
+inline rt_material materialFromMtl(const tinyobj::material_t& t) {
+  rt_material m{};
+  for (int k = 0; k < 3; k++) { m.ka[k] = t.ambient[k]; m.kd[k] = t.diffuse[k]; m.ks[k] = t.specular[k]; }
+  m.ns = t.shininess; m.ni = t.ior > 0.0f ? t.ior : 1.0f;
+  m.type = t.illum == 3 ? 1u : ((t.illum == 4 || t.illum == 6 || t.illum == 7 || t.illum == 9) ? 2u : RT_MATERIAL_TYPE_OF_INSTANCE);
+  return m;
+}
+
 // src/main.cpp:1606-1729 for an arbitrary list of OBJ files ({CENTER, ORBITING} in the reference).
 inline SceneGeometry loadScene(const std::vector<std::string>& fileNames) {
   SceneGeometry g;
+  g.materials.push_back(referenceMaterial());
   tinyobj::ObjReaderConfig reader_config;
   for (const std::string& fileName : fileNames) {
     tinyobj::ObjReader reader;
@@ -88,9 +113,15 @@ inline SceneGeometry loadScene(const std::vector<std::string>& fileNames) {
     r.first_float = g.vertexBuffer.size();
     r.first_index = g.indexBuffer.size();
     uint32_t prims = 0;
+    const uint32_t firstMaterial = (uint32_t)g.materials.size();
+    for (const tinyobj::material_t& mt : reader.GetMaterials()) g.materials.push_back(materialFromMtl(mt));
     for (const tinyobj::shape_t& shape : shapes) {              // src/main.cpp:1643-1650
       prims += (uint32_t)shape.mesh.num_face_vertices.size();
       for (const tinyobj::index_t& index : shape.mesh.indices) g.indexBuffer.push_back((uint32_t)index.vertex_index);
+      for (size_t f = 0; f < shape.mesh.num_face_vertices.size(); f++) {
+        const int id = f < shape.mesh.material_ids.size() ? shape.mesh.material_ids[f] : -1;
+        g.primMaterial.push_back(id >= 0 && (size_t)id < reader.GetMaterials().size() ? firstMaterial + (uint32_t)id : 0u);
+      }
     }
     r.prim_count = prims;
     std::vector<float> tmp;
@@ -180,6 +211,10 @@ class Renderer {
   }
   void setInstances(const std::vector<rt_instance>& inst, bool update) { check(rt_set_instances(ctx_, inst.data(), (int)inst.size(), update ? 1 : 0), "rt_set_instances"); }
   void setUniforms(const rt_uniforms& u) { check(rt_set_uniforms(ctx_, &u), "rt_set_uniforms"); }
+  // row n4: shade with the MTL materials of the loaded OBJ files / give every instance its own type
+  void setMaterials(const SceneGeometry& g) { check(rt_set_materials(ctx_, g.materials.data(), (int)g.materials.size(), g.primMaterial.data(), g.primMaterial.size()), "rt_set_materials"); }
+  void clearMaterials() { check(rt_set_materials(ctx_, nullptr, 0, nullptr, 0), "rt_set_materials"); }
+  void setInstanceTypes(const std::vector<uint32_t>& types) { check(rt_set_instance_types(ctx_, types.data(), (int)types.size()), "rt_set_instance_types"); }
   void setSkybox(const std::vector<std::vector<uint8_t>>& faces, int w, int h) {
     const uint8_t* p[6];
     for (int f = 0; f < 6; f++) p[f] = faces[f].data();

@@ -40,6 +40,10 @@ def _bind(L):
     L.orc_tri_test.argtypes = [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p]
     L.orc_bounce_step.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.orc_render_pixels.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_set_materials.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_uint64]
+    L.orc_set_instance_types.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.orc_pow_int.argtypes = [C.c_float, C.c_uint32]
+    L.orc_pow_int.restype = C.c_float
     L.orc_primary_ray.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     return L
 
@@ -110,6 +114,20 @@ class OracleScene:
         h, w = faces[0].shape[:2]
         arr = (C.c_void_p * 6)(*[f.ctypes.data for f in faces])
         assert self.L.orc_set_skybox(self.h, arr, w, h) == 0
+
+    def set_materials(self, table, prim_material):
+        """table: structured array of 48-byte material records (or None to remove), prim_material: uint32 per triangle"""
+        if table is None or len(table) == 0:
+            assert self.L.orc_set_materials(self.h, None, 0, None, 0) == 0
+            return
+        table = np.ascontiguousarray(table)
+        assert table.dtype.itemsize == 48
+        pm = np.ascontiguousarray(prim_material, np.uint32)
+        assert self.L.orc_set_materials(self.h, _ptr(table), len(table), _ptr(pm), len(pm)) == 0, "orc_set_materials failed"
+
+    def set_instance_types(self, types):
+        t = np.ascontiguousarray(types if types is not None else [], np.uint32)
+        assert self.L.orc_set_instance_types(self.h, _ptr(t) if len(t) else None, len(t)) == 0
 
     def intersect(self, rays8, any_hit=False, use_bvh=True, counts=False):
         rays8 = np.ascontiguousarray(rays8, np.float32).reshape(-1, 8)

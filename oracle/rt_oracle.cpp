@@ -169,6 +169,11 @@ struct Instance {
   uint32_t mesh;
 };
 
+// Row n4: one MTL material; 48 bytes, same layout as the product's rt_material.
+struct Material { float ka[3]; float ns; float kd[3]; float ni; float ks[3]; uint32_t type; };
+static_assert(sizeof(Material) == 48, "material record must be 48 bytes");
+static const uint32_t kTypeOfInstance = 0xFFFFFFFFu;
+
 struct Scene {
   std::vector<float> verts;
   std::vector<uint32_t> idx;
@@ -178,6 +183,9 @@ struct Scene {
   std::vector<uint8_t> sky;  // 6 layers RGBA8
   int sky_w = 0, sky_h = 0;
   bool has_uni = false;
+  std::vector<Material> materials;        // empty: the constants of src/shader.rgen:51-55
+  std::vector<uint32_t> prim_material;    // per triangle of the index buffer
+  std::vector<uint32_t> inst_types;       // per instance; empty: src/shader.rgen:96's two-way switch
 };
 
 // inverse of a row-major 3x4 affine transform, evaluated in binary64 and rounded once
@@ -487,6 +495,19 @@ static inline float pow100(float x) {
   return (x64 * x32) * x4;
 }
 
+// x^n, n = 0..1023: squarings, then the set-bit powers multiplied from the highest bit down; n = 100 gives pow100's
+// (x^64 * x^32) * x^4 bit for bit.
+static inline float pow_int(float x, uint32_t n) {
+  float p[10];
+  p[0] = x;
+  for (int k = 1; k < 10; k++) p[k] = p[k - 1] * p[k - 1];
+  float acc = 1.0f;
+  bool first = true;
+  for (int k = 9; k >= 0; k--)
+    if (n >> k & 1u) { acc = first ? p[k] : acc * p[k]; first = false; }
+  return acc;
+}
+
 struct RayCounts { uint64_t primary = 0, secondary = 0, shadow = 0; };
 
 // One iteration of the bounce loop AFTER traceRayEXT has returned (src/shader.rgen:89-177), split from the loop so that
@@ -499,6 +520,7 @@ struct Step {
   V3 sky;                        // STEP_SKY: tmpColor = texture(...)                        (src/shader.rgen:90-94)
   V3 so, sl; float stmax;        // STEP_SHADOW: the shadow ray                              (src/shader.rgen:107-112)
   V3 lit;                        // STEP_SHADOW: tmpColor if the shadow ray reports no occluder (src/shader.rgen:114-129)
+  V3 ambient;                    // STEP_SHADOW: tmpColor if it is occluded = Iamb*ka (of the hit material when a table is set)
   V3 no, nd;                     // STEP_CONTINUE: next rayOrigin / rayDirection             (src/shader.rgen:132-165)
 };
 static const V3 kAmbient = {0.08f, 0.24f, 0.08f};   // Iamb*ka as folded by glslang in shaders/shader.rgen.spv (0x3da3d70a, 0x3e75c28f)
@@ -511,7 +533,13 @@ static Step bounce_step(const Scene& s, V3 o, V3 d, uint32_t i, bool hit, const 
   V3 P, N; int objectIndex;
   closest_hit_attributes(s, h, P, N, objectIndex);
   st.P = P; st.N = N; st.objectIndex = objectIndex;
-  uint32_t type = objectIndex == 0 ? U.centerObjectType : U.orbitingObjectType;
+  uint32_t type = (size_t)h.inst < s.inst_types.size() ? s.inst_types[h.inst] : (objectIndex == 0 ? U.centerObjectType : U.orbitingObjectType);
+  const Material* M = nullptr;   // row n4: the hit triangle's MTL material, if the host supplied a table
+  if (!s.materials.empty()) {
+    const Mesh& mesh = s.meshes[s.inst[h.inst].mesh];
+    M = &s.materials[s.prim_material[mesh.first_index / 3 + (uint32_t)h.prim]];
+    if (M->type != kTypeOfInstance) type = M->type;
+  }
   st.kind = STEP_CONTINUE;
   if (type == 0) {
     if (dot3(d, N) >= 0.0f) { st.kind = STEP_BACKFACE; return st; }
@@ -523,12 +551,16 @@ static Step bounce_step(const Scene& s, V3 o, V3 d, uint32_t i, bool hit, const 
     st.sl = L; st.stmax = dist;
     V3 Hh = normalize3(L + neg(d));
     float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
-    float dl = std::max(0.0f, NdotL), sp = pow100(std::max(0.0f, NdotH));
+    float dl = std::max(0.0f, NdotL);
+    float sp = M ? pow_int(std::max(0.0f, NdotH), (uint32_t)M->ns) : pow100(std::max(0.0f, NdotH));
     float w = 1.0f; for (uint32_t k = 0; k < i; k++) w = w * 0.9f;  // pow(0.9, float(i)), i = SAMPLE index
     float I = U.lightIntensity;
-    V3 diff = mk((I * 0.2f) * dl, (I * 1.0f) * dl, (I * 0.2f) * dl);
-    V3 spec = mk((I * 0.8f) * sp, (I * 0.8f) * sp, (I * 0.8f) * sp);
-    st.lit = fma3(w, diff + spec, kAmbient);   // tmpColor still holds Iamb*ka here: nothing else adds to it
+    V3 kd = M ? mk(M->kd[0], M->kd[1], M->kd[2]) : mk(0.2f, 1.0f, 0.2f);
+    V3 ks = M ? mk(M->ks[0], M->ks[1], M->ks[2]) : mk(0.8f, 0.8f, 0.8f);
+    V3 diff = mk((I * kd.x) * dl, (I * kd.y) * dl, (I * kd.z) * dl);
+    V3 spec = mk((I * ks.x) * sp, (I * ks.y) * sp, (I * ks.z) * sp);
+    st.ambient = M ? mk(0.8f * M->ka[0], 0.8f * M->ka[1], 0.8f * M->ka[2]) : kAmbient;   // Iamb * ka
+    st.lit = fma3(w, diff + spec, st.ambient);   // tmpColor holds Iamb*ka here: nothing else adds to it
   } else if (type == 1) {
     st.no = fma3(0.01f, N, P);
     st.nd = reflect3(d, N);
@@ -536,7 +568,7 @@ static Step bounce_step(const Scene& s, V3 o, V3 d, uint32_t i, bool hit, const 
     float ndoti = dot3(d, N);
     bool outwards = ndoti > 0.0f;
     if (outwards) { N = neg(N); ndoti = -ndoti; }
-    float ratio = outwards ? 1.52f : (1.0f / 1.52f);
+    float ratio = M ? (outwards ? M->ni : 1.0f / M->ni) : (outwards ? 1.52f : (1.0f / 1.52f));
     float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
     if (k < 0.0f) { st.nd = reflect3(d, N); st.no = fma3(0.01f, N, P); }
     else {
@@ -576,7 +608,7 @@ static V3 shade_sample(const Scene& s, uint32_t px, uint32_t py, uint32_t W, uin
       Hit sh;
       rc.shadow++;
       bool occ = trace(s, st.so, st.sl, 0.001f, st.stmax, true, use_bvh, sh, cnt);
-      if (!occ) tmp = st.lit;
+      tmp = occ ? st.ambient : st.lit;
       break;
     }
     o = st.no; d = st.nd;
@@ -739,6 +771,25 @@ int orc_render_pixels(void* p, uint32_t W, uint32_t H, uint64_t n, const uint32_
   }
   return 0;
 }
+
+// row n4: material table + per-triangle material ids (n_materials == 0 removes them), per-instance types (n == 0 removes them)
+int orc_set_materials(void* p, const Material* table, int n_materials, const uint32_t* prim_material, uint64_t n_prims) {
+  Scene& s = *(Scene*)p;
+  s.materials.clear(); s.prim_material.clear();
+  if (n_materials <= 0) return 0;
+  if (n_prims != s.idx.size() / 3) return 1;
+  for (uint64_t k = 0; k < n_prims; k++) if (prim_material[k] >= (uint32_t)n_materials) return 1;
+  s.materials.assign(table, table + n_materials);
+  for (auto& m : s.materials) m.ns = floorf(std::min(std::max(m.ns, 0.0f), 1023.0f) + 0.5f);
+  s.prim_material.assign(prim_material, prim_material + n_prims);
+  return 0;
+}
+int orc_set_instance_types(void* p, const uint32_t* types, int n) {
+  Scene& s = *(Scene*)p;
+  s.inst_types.assign(types, types + (n > 0 ? n : 0));
+  return 0;
+}
+float orc_pow_int(float x, uint32_t n) { return pow_int(x, n); }
 
 float orc_jitter(float px, float py, float seed) { return jitter_hash(px, py, seed); }
 double orc_sin(double x) { return canon_sin(x); }

@@ -57,6 +57,17 @@ class ScenePair:
         if self.ctx is not None:
             self.ctx.set_uniforms(uniforms)
 
+    def set_materials(self, table, prim_material=None):
+        """row n4: the same MTL material table for the oracle and the product (None removes it)"""
+        self.orc.set_materials(table, prim_material)
+        if self.ctx is not None:
+            self.ctx.set_materials(table, prim_material)
+
+    def set_instance_types(self, types):
+        self.orc.set_instance_types(types)
+        if self.ctx is not None:
+            self.ctx.set_instance_types(types)
+
     def set_instances(self, instances, update=False):
         self.instances = np.ascontiguousarray(instances, INSTANCE_DTYPE)
         self.orc.set_instances([self.instances[i].tobytes() for i in range(len(self.instances))])

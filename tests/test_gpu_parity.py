@@ -908,3 +908,70 @@ def test_cube_seams_and_corners_on_the_gpu(ctx):
         assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
         seen += 1
     assert seen == 5
+
+
+def test_row_n4_mtl_materials_and_instance_types(ctx):
+    """SURVEY.md §8(f) n4 on the HIP path: (a) cube_scene.obj shaded with the 8 materials of its own cube_scene.mtl (per-face
+    usemtl -> Ka/Kd/Ks/Ns per triangle); (b) five instances with per-instance types (diffuse / mirror / refractive) instead of
+    the reference's two-way switch, materials with their own Ni and an illum-style forced type — all against the oracle;
+    (c) removing table and types gives the reference's frame again, bit for bit."""
+    from vulkan_raytracing_amd.api import MATERIAL_TYPE_OF_INSTANCE
+    c2 = RtContext(0)
+    try:
+        inst = [host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)]
+        u = host.default_uniforms(max_bounce_count=2, samples_per_pixel=2, center_object_type=0, orbiting_object_type=0)
+        sp = scenes.ScenePair([os.path.join(RES, "cube_scene.obj")], inst, u, sky=scenes.synthetic_skybox(64), ctx=c2)
+        W, H = 256, 256
+        base, _ = c2.trace(W, H)
+        g = sp.geom
+        assert len(g.materials) == 9
+        sp.set_materials(g.materials, g.prim_material)
+        gpu, st = c2.trace(W, H)
+        ref, rc = sp.orc.render(W, H)
+        check_image(gpu, ref)
+        assert np.abs(gpu - base).max() > 0.05 and (st.rays_primary, st.rays_secondary, st.rays_shadow) == tuple(int(x) for x in rc)
+        # (b) teapot + cube meshes, five instances, types per instance, a glass material with Ni 1.2 and a forced-mirror material
+        paths = [os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj")]
+        inst5 = np.zeros(5, scenes.INSTANCE_DTYPE)
+        place = [((0, 0, 0), 0, 0), ((-4.5, 0, 2), 1, 1), ((4.5, 0.5, 2), 1, 1), ((0, -3.5, 3), 1, 1), ((0, 3.5, 1), 1, 0)]
+        for k, (t, ci, mesh) in enumerate(place):
+            inst5[k] = host.make_instance(np.array([1, 0, 0, t[0], 0, 1, 0, t[1], 0, 0, 1, t[2]], np.float32), ci, mesh)
+        geom = host.SceneGeometry(paths)
+        u5 = host.default_uniforms(max_bounce_count=4, samples_per_pixel=2, center_object_type=1, orbiting_object_type=0,
+                                   orbiting_object_primitive_offset=geom.orbiting_primitive_offset, orbiting_object_vertex_offset=geom.orbiting_vertex_offset)
+        sp5 = scenes.ScenePair(paths, inst5, u5, sky=scenes.synthetic_skybox(64), ctx=c2)
+        before, _ = c2.trace(320, 200)
+        tbl = sp5.geom.materials.copy()                     # 0 = reference surface, 1 = teapot.mtl, 2 = cube.mtl (if any)
+        assert len(tbl) >= 2
+        tbl["kd"][1] = (0.9, 0.3, 0.1); tbl["ns"][1] = 37.0; tbl["ni"][1] = 1.2; tbl["ka"][1] = (0.2, 0.1, 0.05)
+        pm = sp5.geom.prim_material.copy()
+        # the cube's bottom half of triangles becomes a forced mirror (as `illum 3` would), the rest the reference surface
+        cube_first = sp5.geom.ranges[1][1] // 3
+        forced = np.zeros(1, tbl.dtype); forced[0] = tbl[0]; forced["type"] = 1
+        tbl = np.concatenate([tbl, forced])
+        pm[cube_first:cube_first + 6] = len(tbl) - 1
+        pm[cube_first + 6:] = 0
+        sp5.set_materials(tbl, pm)
+        sp5.set_instance_types([2, 0, 1, 2, 0])
+        gpu5, st5 = c2.trace(320, 200)
+        ref5, rc5 = sp5.orc.render(320, 200)
+        check_image(gpu5, ref5)
+        assert (st5.rays_primary, st5.rays_secondary, st5.rays_shadow) == tuple(int(x) for x in rc5)
+        assert np.abs(gpu5 - before).max() > 0.05 and st5.rays_secondary > 0 and st5.rays_shadow > 0
+        # the other traversal variants shade through the same code
+        for v in (2, 1):
+            c2.set_param("trace_variant", v)
+            img, _ = c2.trace(320, 200)
+            assert np.array_equal(img, gpu5), v
+        c2.set_param("trace_variant", 0)
+        # (c) back to the reference
+        sp5.set_materials(None)
+        sp5.set_instance_types(None)
+        after, _ = c2.trace(320, 200)
+        assert np.array_equal(after, before)
+        with pytest.raises(RtError):
+            c2.set_materials(tbl, pm[:-1])                  # one id per triangle of the index buffer
+        with pytest.raises(RtError):
+            c2.set_instance_types([0, 3])
+    finally:
+        c2.close()

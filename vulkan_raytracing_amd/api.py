@@ -13,6 +13,9 @@ UNIFORMS_DTYPE = np.dtype([("position", np.float32, 4), ("right", np.float32, 4)
                            ("max_bounce_count", np.uint32), ("samples_per_pixel", np.uint32),
                            ("center_object_type", np.uint32), ("orbiting_object_type", np.uint32),
                            ("orbiting_object_primitive_offset", np.uint32), ("orbiting_object_vertex_offset", np.uint32)])
+MATERIAL_DTYPE = np.dtype([("ka", np.float32, 3), ("ns", np.float32), ("kd", np.float32, 3), ("ni", np.float32), ("ks", np.float32, 3), ("type", np.uint32)])
+MATERIAL_TYPE_OF_INSTANCE = 0xFFFFFFFF
+assert MATERIAL_DTYPE.itemsize == 48
 assert INSTANCE_DTYPE.itemsize == 64 and UNIFORMS_DTYPE.itemsize == 104 and MESH_RANGE_DTYPE.itemsize == 24
 
 
@@ -33,7 +36,7 @@ class RtStats(C.Structure):
         return self.rays_primary + self.rays_secondary + self.rays_shadow
 
 
-EXPORTS = ["rt_create", "rt_create_frame_slot", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_uniforms", "rt_set_skybox",
+EXPORTS = ["rt_create", "rt_create_frame_slot", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_materials", "rt_set_instance_types", "rt_set_uniforms", "rt_set_skybox",
            "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_assemble_shards", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
            "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_debug_sizing", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
@@ -52,6 +55,8 @@ def lib():
         L.rt_upload_geometry.argtypes = [vp, vp, C.c_size_t, vp, C.c_size_t, vp, C.c_int]
         L.rt_build_blas.argtypes = [vp, C.c_int]
         L.rt_set_instances.argtypes = [vp, vp, C.c_int, C.c_int]
+        L.rt_set_materials.argtypes = [vp, vp, C.c_int, vp, C.c_size_t]
+        L.rt_set_instance_types.argtypes = [vp, vp, C.c_int]
         L.rt_set_uniforms.argtypes = [vp, vp]
         L.rt_set_skybox.argtypes = [vp, C.POINTER(vp), C.c_int, C.c_int]
         L.rt_trace.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(RtStats)]
@@ -144,6 +149,19 @@ class RtContext:
     def set_instances(self, instances, update=False):
         inst = np.ascontiguousarray(instances, INSTANCE_DTYPE)
         self._chk(self.L.rt_set_instances(self.h, _p(inst), len(inst), int(update)), "rt_set_instances")
+
+    def set_materials(self, table, prim_material=None):
+        """row n4: MTL material table + material id of every triangle of the index buffer; table None/empty removes it"""
+        if table is None or len(table) == 0:
+            self._chk(self.L.rt_set_materials(self.h, None, 0, None, 0), "rt_set_materials")
+            return
+        t = np.ascontiguousarray(table, MATERIAL_DTYPE)
+        pm = np.ascontiguousarray(prim_material, np.uint32)
+        self._chk(self.L.rt_set_materials(self.h, _p(t), len(t), _p(pm), len(pm)), "rt_set_materials")
+
+    def set_instance_types(self, types):
+        t = np.ascontiguousarray(types if types is not None else [], np.uint32)
+        self._chk(self.L.rt_set_instance_types(self.h, _p(t) if len(t) else None, len(t)), "rt_set_instance_types")
 
     def set_uniforms(self, uniforms):
         u = np.ascontiguousarray(uniforms, UNIFORMS_DTYPE).reshape(1)

@@ -26,6 +26,10 @@ int rth_scene_n_meshes(void* s) { return (int)((rthost::SceneGeometry*)s)->range
 const float* rth_scene_verts(void* s) { return ((rthost::SceneGeometry*)s)->vertexBuffer.data(); }
 const uint32_t* rth_scene_idx(void* s) { return ((rthost::SceneGeometry*)s)->indexBuffer.data(); }
 const rt_mesh_range* rth_scene_ranges(void* s) { return ((rthost::SceneGeometry*)s)->ranges.data(); }
+int rth_scene_n_materials(void* s) { return (int)((rthost::SceneGeometry*)s)->materials.size(); }
+const rt_material* rth_scene_materials(void* s) { return ((rthost::SceneGeometry*)s)->materials.data(); }
+uint64_t rth_scene_n_prim_material(void* s) { return ((rthost::SceneGeometry*)s)->primMaterial.size(); }
+const uint32_t* rth_scene_prim_material(void* s) { return ((rthost::SceneGeometry*)s)->primMaterial.data(); }
 uint32_t rth_scene_orbit_prim_offset(void* s) { return ((rthost::SceneGeometry*)s)->orbitingObjectPrimitiveOffset(); }
 uint32_t rth_scene_orbit_vert_offset(void* s) { return ((rthost::SceneGeometry*)s)->orbitingObjectVertexOffset(); }
 

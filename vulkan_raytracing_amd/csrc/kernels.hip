@@ -101,6 +101,26 @@ __device__ __forceinline__ float pow100(float x) {
   float x2 = x * x, x4 = x2 * x2, x8 = x4 * x4, x16 = x8 * x8, x32 = x16 * x16, x64 = x32 * x32;
   return (x64 * x32) * x4;
 }
+// x^n for an integer exponent 0..1023 (row n4: the MTL's Ns): the powers x^(2^k) by repeated squaring, multiplied together
+// from the HIGHEST set bit down — for n = 100 exactly pow100's (x^64 * x^32) * x^4.  Same order in the oracle.
+__device__ __forceinline__ float pow_int(float x, uint32_t n) {
+  float p[10];
+  p[0] = x;
+#pragma unroll
+  for (int k = 1; k < 10; k++) p[k] = p[k - 1] * p[k - 1];
+  float acc = 1.0f;
+  bool first = true;
+#pragma unroll
+  for (int k = 9; k >= 0; k--)
+    if (n >> k & 1u) { acc = first ? p[k] : acc * p[k]; first = false; }
+  return acc;
+}
+// Iamb * ka of the material a shadow-queue entry was tagged with (MATERIAL_NONE: the folded constant of shader.rgen.spv)
+__device__ __forceinline__ F3 ambient_of(const SceneDev& sc, uint32_t mat) {
+  if (mat == MATERIAL_NONE) return mk3(0.08f, 0.24f, 0.08f);
+  const MaterialDev* M = sc.materials + mat;
+  return mk3(0.8f * M->ka[0], 0.8f * M->ka[1], 0.8f * M->ka[2]);
+}
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers (wave64)
@@ -458,10 +478,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       else if (MODE == MODE_SHADOW) {
         // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit.  The light term of the
         // shadow-queue entry is fetched here, once per result burst, instead of riding along in registers.
+        // (the entry holds tmpColor for the lit case; the shadowed case keeps Iamb*ka — of the tagged material when a table is set)
         float cr = 0.08f, cg = 0.24f, cb = 0.08f;
-        if (r.x != 0.0f) {
+        if (r.x != 0.0f || a.sc.n_materials != 0) {
           const float4 shc = a.sh_c[(uint32_t)k.y];
-          cr = __builtin_fmaf(shc.w, shc.x, cr); cg = __builtin_fmaf(shc.w, shc.y, cg); cb = __builtin_fmaf(shc.w, shc.z, cb);
+          if (r.x != 0.0f) { cr = shc.x; cg = shc.y; cb = shc.z; }
+          else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); cr = amb.x; cg = amb.y; cb = amb.z; }
         }
         a.sample_color[(uint32_t)k.x] = make_float4(cr, cg, cb, 1.0f);
       }
@@ -952,8 +974,9 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
         const uint32_t slot = out_count + (prefix_rank(fin_mask) >> 2);
         if (MODE == MODE_SHADOW) {
           // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
-          float r = 0.08f, g = 0.24f, b = 0.08f;
-          if (best_inst < 0) { r = __builtin_fmaf(shc.w, shc.x, r); g = __builtin_fmaf(shc.w, shc.y, g); b = __builtin_fmaf(shc.w, shc.z, b); }
+          float r, g, b;
+          if (best_inst < 0) { r = shc.x; g = shc.y; b = shc.z; }
+          else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); r = amb.x; g = amb.y; b = amb.z; }
           s_out[wave][slot] = make_float4(r, g, b, 1.0f);
           s_outq[wave][slot] = make_int2((int)sid, 0);
         } else {
@@ -1043,7 +1066,16 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
         const F3 P = xform_point(I->o2w, pos);
         F3 N = normalize3(xform_normal(I->w2o, nrm));
         const int objectIndex = I->custom_index;
-        const uint32_t type = objectIndex == 0 ? U.center_object_type : U.orbiting_object_type;
+        // src/shader.rgen:96, generalised (row n4): a per-instance type replaces the two-way switch when the host set one,
+        // and an MTL material may fix its own type (illum)
+        uint32_t type = I->type != TYPE_BY_OBJECT_INDEX ? I->type : (objectIndex == 0 ? U.center_object_type : U.orbiting_object_type);
+        const MaterialDev* M = nullptr;
+        uint32_t mat = MATERIAL_NONE;
+        if (a.sc.n_materials != 0) {
+          mat = a.sc.prim_material[I->first_index / 3u + prim];
+          M = a.sc.materials + mat;
+          if (M->type != TYPE_BY_INSTANCE) type = M->type;
+        }
         const bool last = (uint32_t)a.bounce >= U.max_bounce_count;
         if (type == 0u) {
           // src/shader.rgen:97-131
@@ -1056,14 +1088,18 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
             const F3 L = mul3(toL, 1.0f / dist);
             const F3 Hh = normalize3(add3(L, neg3(d)));
             const float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
-            const float dl = fmaxf(0.0f, NdotL), sp = pow100(fmaxf(0.0f, NdotH));
+            const float dl = fmaxf(0.0f, NdotL);
+            const float sp = M ? pow_int(fmaxf(0.0f, NdotH), (uint32_t)M->ns) : pow100(fmaxf(0.0f, NdotH));
             const uint32_t i = sid / (uint32_t)(f.rows * f.width);
             float w = 1.0f;
             for (uint32_t k = 0; k < i; k++) w = w * 0.9f;
             const float Iv = U.light_intensity;
-            const F3 diff = mk3((Iv * 0.2f) * dl, (Iv * 1.0f) * dl, (Iv * 0.2f) * dl);
-            const float sv = (Iv * 0.8f) * sp;
-            sh_c = add3(diff, mk3(sv, sv, sv)); sh_w = w;
+            const F3 kd = M ? mk3(M->kd[0], M->kd[1], M->kd[2]) : mk3(0.2f, 1.0f, 0.2f);
+            const F3 ks = M ? mk3(M->ks[0], M->ks[1], M->ks[2]) : mk3(0.8f, 0.8f, 0.8f);
+            const F3 diff = mk3((Iv * kd.x) * dl, (Iv * kd.y) * dl, (Iv * kd.z) * dl);
+            const F3 spec = mk3((Iv * ks.x) * sp, (Iv * ks.y) * sp, (Iv * ks.z) * sp);
+            // tmpColor += pow(0.9, i) * (diffuse + specular) on top of Iamb*ka; the shadow kernel writes it if the light is visible
+            sh_c = fma3(w, add3(diff, spec), ambient_of(a.sc, mat)); sh_w = __uint_as_float(mat);
             nd = L; sh_tmax = dist;
             push_shadow = true;
           }
@@ -1077,7 +1113,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
           float ndoti = dot3(d, N);
           const bool outwards = ndoti > 0.0f;
           if (outwards) { N = neg3(N); ndoti = -ndoti; }
-          const float ratio = outwards ? 1.52f : (1.0f / 1.52f);
+          const float ratio = M ? (outwards ? M->ni : 1.0f / M->ni) : (outwards ? 1.52f : (1.0f / 1.52f));
           const float k = 1.0f - (ratio * ratio) * (1.0f - ndoti * ndoti);
           if (k < 0.0f) { nd = reflect3(d, N); no = fma3(0.01f, N, P); }
           else {

@@ -26,6 +26,7 @@ static_assert(sizeof(rt_uniforms) == 104, "rt_uniforms must mirror UniformStruct
 static_assert(sizeof(rt_uniforms) == sizeof(UniformsDev), "uniform mirrors out of sync");
 static_assert(sizeof(rt_hit) == sizeof(HitRec), "hit mirrors out of sync");
 static_assert(sizeof(rt_mesh_range) == 24, "rt_mesh_range layout");
+static_assert(sizeof(rt_material) == sizeof(MaterialDev), "material mirrors out of sync");
 
 namespace {
 
@@ -85,6 +86,12 @@ struct Scene {
   // cube map (binding 5)
   uchar4* d_sky = nullptr;
   int sky_w = 0, sky_h = 0;
+
+  // row n4: MTL materials (none: the reference's hard-coded constants)
+  MaterialDev* d_materials = nullptr;
+  uint32_t* d_prim_material = nullptr;
+  int n_materials = 0;
+  size_t n_prim_material = 0;
 };
 
 struct rt_ctx {
@@ -98,6 +105,7 @@ struct rt_ctx {
 
   // instances / TLAS (binding 0) of this slot
   std::vector<rt_instance> h_inst;
+  std::vector<uint32_t> inst_types;   // rt_set_instance_types: per-instance object type (empty: src/shader.rgen:96's two-way switch)
   BuiltBvh tlas;
   Bvh4 tlas4;
   bool tlas_valid = false;
@@ -381,6 +389,7 @@ SceneDev scene_dev(const rt_ctx* c) {
   s.blas_nodes = S->d_blas_nodes; s.tlas_root = (int)tlas_base(c); s.tris = S->d_tris; s.inst = c->d_inst;
   s.verts = S->d_verts; s.idx = S->d_idx; s.sky = S->d_sky; s.n_inst = (int)c->h_inst.size();
   s.sky_w = S->sky_w; s.sky_h = S->sky_h;
+  s.materials = S->d_materials; s.prim_material = S->d_prim_material; s.n_materials = S->n_materials;
   for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
   return s;
 }
@@ -600,7 +609,7 @@ int collect_stats(rt_ctx* c) {
 // ================================================================================================
 extern "C" {
 
-int rt_abi_version(void) { return 3; }   // 2: rt_trace_async / rt_trace_wait, rt_stats::ms_tail; 3: rt_stats::tail_faults, rt_debug_sizing
+int rt_abi_version(void) { return 4; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials
 
 static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
@@ -676,7 +685,7 @@ void rt_destroy(rt_ctx* c) {
   S->members.erase(std::remove(S->members.begin(), S->members.end(), c), S->members.end());
   S->slot_mask &= ~(1u << c->slot);
   if (S->members.empty()) {   // the last context of a scene takes the shared arrays with it
-    void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky};
+    void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky, S->d_materials, S->d_prim_material};
     for (void* p : sp) if (p) hipFree(p);
     delete S;
   }
@@ -714,6 +723,10 @@ int rt_upload_geometry(rt_ctx* c, const float* verts6, size_t n_floats, const ui
   S->meshes.assign(n_meshes, Mesh{});
   for (int m = 0; m < n_meshes; m++) S->meshes[m].range = ranges[m];
   S->blas_linked = false; invalidate_tlas(S);
+  // the per-triangle material ids belong to the old index buffer
+  if (S->d_materials) { HIP_TRY(c, hipFree(S->d_materials)); S->d_materials = nullptr; }
+  if (S->d_prim_material) { HIP_TRY(c, hipFree(S->d_prim_material)); S->d_prim_material = nullptr; }
+  S->n_materials = 0; S->n_prim_material = 0;
   return RT_OK;
 }
 
@@ -781,7 +794,8 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     d.custom_index = (int32_t)(inst[i].custom_index_and_mask & 0xFFFFFFu);
     d.first_float = (uint32_t)m.range.first_float;
     d.first_index = (uint32_t)m.range.first_index;
-    d.pad[0] = d.pad[1] = d.pad[2] = d.pad[3] = 0;
+    d.type = (size_t)i < c->inst_types.size() ? c->inst_types[i] : TYPE_BY_OBJECT_INDEX;
+    d.pad[0] = d.pad[1] = d.pad[2] = 0;
     boxes[i] = instance_world_box(d.o2w, m.bounds);
   }
   if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
@@ -806,6 +820,58 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
                     " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
   int r = upload_instances(c, inst_dev); if (r) return r;
   c->tlas_valid = true;
+  return RT_OK;
+}
+
+// Row n4: the MTL materials the reference's loader parses and its renderer ignores (src/shader.rgen:51-55
+// hard-codes kd, ks, 100, 1.52).  table[prim_material[g]] shades triangle g of the index buffer (g = first_index / 3 +
+// gl_PrimitiveID).  n_materials == 0 removes the table: the reference's constants again.
+int rt_set_materials(rt_ctx* c, const rt_material* table, int n_materials, const uint32_t* prim_material, size_t n_prims) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (n_materials < 0 || (n_materials > 0 && (!table || !prim_material))) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_set_materials arguments");
+  { int q = quiesce_scene(c); if (q) return q; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  Scene* S = c->scene;
+  if (n_materials > 0) {
+    if (!S->d_idx) return fail(c, RT_ERR_NOT_READY, "rt_upload_geometry has not been called");
+    if (n_prims != S->h_idx.size() / 3) return fail(c, RT_ERR_INVALID_ARGUMENT, "prim_material needs one entry per triangle of the index buffer (" + std::to_string(S->h_idx.size() / 3) + ")");
+    for (size_t k = 0; k < n_prims; k++)
+      if (prim_material[k] >= (uint32_t)n_materials) return fail(c, RT_ERR_INVALID_ARGUMENT, "material index out of range at triangle " + std::to_string(k));
+    for (int m = 0; m < n_materials; m++) {
+      const rt_material& t = table[m];
+      if (!(t.type <= 2u || t.type == TYPE_BY_INSTANCE)) return fail(c, RT_ERR_INVALID_ARGUMENT, "material " + std::to_string(m) + ": type must be 0, 1, 2 or RT_MATERIAL_TYPE_OF_INSTANCE");
+      if (!(t.ni > 0.0f) || !(t.ns >= 0.0f)) return fail(c, RT_ERR_INVALID_ARGUMENT, "material " + std::to_string(m) + ": Ni must be > 0 and Ns >= 0");
+    }
+  }
+  if (S->d_materials) { HIP_TRY(c, hipFree(S->d_materials)); S->d_materials = nullptr; }
+  if (S->d_prim_material) { HIP_TRY(c, hipFree(S->d_prim_material)); S->d_prim_material = nullptr; }
+  S->n_materials = 0; S->n_prim_material = 0;
+  if (n_materials == 0) return RT_OK;
+  std::vector<MaterialDev> dev(n_materials);
+  for (int m = 0; m < n_materials; m++) {
+    memcpy(&dev[m], &table[m], sizeof(MaterialDev));
+    dev[m].ns = std::floor(std::min(std::max(table[m].ns, 0.0f), 1023.0f) + 0.5f);   // the exponent is applied as an integer power
+  }
+  HIP_TRY(c, hipMalloc((void**)&S->d_materials, dev.size() * sizeof(MaterialDev)));
+  HIP_TRY(c, hipMalloc((void**)&S->d_prim_material, std::max<size_t>(1, n_prims) * sizeof(uint32_t)));
+  HIP_TRY(c, hipMemcpy(S->d_materials, dev.data(), dev.size() * sizeof(MaterialDev), hipMemcpyHostToDevice));
+  if (n_prims) HIP_TRY(c, hipMemcpy(S->d_prim_material, prim_material, n_prims * sizeof(uint32_t), hipMemcpyHostToDevice));
+  S->n_materials = n_materials; S->n_prim_material = n_prims;
+  return RT_OK;
+}
+
+// Per-instance object type (0 diffuse, 1 mirror, 2 refractive) for this context's instances, replacing the reference's
+// "objectIndex == 0 ? centerObjectType : orbitingObjectType" (src/shader.rgen:96, "Hardcoded as 2 objects" src/main.cpp:2425).
+// Takes effect with the next rt_set_instances; n == 0 restores the two-way switch.
+int rt_set_instance_types(rt_ctx* c, const uint32_t* types, int n) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (n < 0 || (n > 0 && !types)) return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_set_instance_types arguments");
+  for (int i = 0; i < n; i++) if (types[i] > 2u) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance type must be 0, 1 or 2");
+  c->inst_types.assign(types, types + n);
+  if (c->tlas_valid && !c->h_inst.empty()) {   // re-issue the instance records with the new types
+    std::vector<rt_instance> keep = c->h_inst;
+    return rt_set_instances(c, keep.data(), (int)keep.size(), 1);
+  }
   return RT_OK;
 }
 

@@ -88,7 +88,8 @@ struct alignas(16) InstanceDev {
   int32_t blas_root4;   // root of the mesh in nodes4 (BVH4)
   float q_lo[3];        // dequantisation of the mesh's BvhNodeQ planes (object space)
   float q_scale[3];
-  uint32_t pad[4];
+  uint32_t type;        // per-instance object type (rt_set_instance_types) or TYPE_BY_OBJECT_INDEX: the reference's two-way switch
+  uint32_t pad[3];
 };
 static_assert(sizeof(InstanceDev) == 160, "InstanceDev must be 160 bytes");
 
@@ -103,6 +104,18 @@ struct UniformsDev {
 static_assert(sizeof(UniformsDev) == 104, "UniformsDev must be 104 bytes");
 
 struct HitRec { float t, u, v; int32_t prim, inst; };  // == rt_hit
+
+// Row n4: one MTL material (== rt_material, 48 B).  Without a table the kernels use the constants the reference hard-codes
+// (src/shader.rgen:51-55: ka .1 .3 .1, kd .2 1 .2, ks .8, exponent 100, index of refraction 1.52).
+struct MaterialDev {
+  float ka[3]; float ns;
+  float kd[3]; float ni;
+  float ks[3]; uint32_t type;   // 0 diffuse, 1 mirror, 2 refractive, TYPE_BY_INSTANCE: the instance decides
+};
+static_assert(sizeof(MaterialDev) == 48, "MaterialDev must be 48 bytes");
+constexpr uint32_t TYPE_BY_OBJECT_INDEX = 0xFFFFFFFFu;   // InstanceDev::type: objectIndex == 0 ? centerObjectType : orbitingObjectType
+constexpr uint32_t TYPE_BY_INSTANCE = 0xFFFFFFFFu;       // MaterialDev::type
+constexpr uint32_t MATERIAL_NONE = 0xFFFFFFFFu;          // shadow-queue tag: the reference's constant ambient term
 
 // ---- queues and counters ---------------------------------------------------------------------
 // Every ray queue is split into N_SHARDS regions of `shard_cap` entries (entry v = shard*shard_cap +

@@ -22,6 +22,9 @@ struct SceneDev {
   int n_inst;
   int sky_w, sky_h;
   uint32_t ovf_stride;         // spill entries per lane behind the LDS stack, sized from the depth of the trees
+  const MaterialDev* materials;   // row n4: MTL material table (NULL / n_materials == 0: the reference's hard-coded constants)
+  const uint32_t* prim_material;  // material of every triangle of the index buffer (global primitive number = first_index / 3 + gl_PrimitiveID)
+  int n_materials;
 };
 
 struct FrameDev {
@@ -31,7 +34,7 @@ struct FrameDev {
   int32_t* hit_inst;           //                       instance index, -1 = miss
   float4* sh_o;                // shadow queue: (o.xyz, tmax = lightDistance)
   float4* sh_d;                //               (L.xyz, sample id bits)
-  float4* sh_c;                //               (diffuse+specular rgb, 0.9^i)
+  float4* sh_c;                //               (tmpColor if the light is visible: rgb, material tag bits)
   float4* sample_color;        // per-sample tmpColor (rgb, 1), index = i*(rows*W) + ly*W + x
   uint32_t* counters;          // rt::CNT_* layout
   int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread

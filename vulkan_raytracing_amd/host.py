@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 from . import _native
-from .api import INSTANCE_DTYPE, MESH_RANGE_DTYPE, UNIFORMS_DTYPE
+from .api import INSTANCE_DTYPE, MATERIAL_DTYPE, MESH_RANGE_DTYPE, UNIFORMS_DTYPE
 
 _H = None
 SKYBOX_FACES = ("right", "left", "top", "bottom", "front", "back")  # src/main.cpp:2064-2071
@@ -26,6 +26,7 @@ def hlib():
         L.rth_scene_free.argtypes = [vp]
         for fn, rt in (("rth_scene_n_floats", C.c_uint64), ("rth_scene_n_idx", C.c_uint64), ("rth_scene_n_meshes", C.c_int),
                        ("rth_scene_verts", vp), ("rth_scene_idx", vp), ("rth_scene_ranges", vp),
+                       ("rth_scene_n_materials", C.c_int), ("rth_scene_materials", vp), ("rth_scene_n_prim_material", C.c_uint64), ("rth_scene_prim_material", vp),
                        ("rth_scene_orbit_prim_offset", C.c_uint32), ("rth_scene_orbit_vert_offset", C.c_uint32)):
             getattr(L, fn).argtypes = [vp]
             getattr(L, fn).restype = rt
@@ -73,6 +74,10 @@ class SceneGeometry:
             rbuf = C.string_at(L.rth_scene_ranges(h), nm * MESH_RANGE_DTYPE.itemsize)
             r = np.frombuffer(rbuf, MESH_RANGE_DTYPE)
             self.ranges = [(int(x["first_float"]), int(x["first_index"]), int(x["prim_count"])) for x in r]
+            # row n4: the MTL materials the loader parsed (entry 0 = the reference's hard-coded surface) and each triangle's material
+            nmat, npm = L.rth_scene_n_materials(h), L.rth_scene_n_prim_material(h)
+            self.materials = np.frombuffer(C.string_at(L.rth_scene_materials(h), nmat * MATERIAL_DTYPE.itemsize), MATERIAL_DTYPE).copy()
+            self.prim_material = np.ctypeslib.as_array(C.cast(L.rth_scene_prim_material(h), C.POINTER(C.c_uint32)), (npm,)).copy() if npm else np.zeros(0, np.uint32)
             self.orbiting_primitive_offset = L.rth_scene_orbit_prim_offset(h)
             self.orbiting_vertex_offset = L.rth_scene_orbit_vert_offset(h)
         finally:
