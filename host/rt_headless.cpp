@@ -217,7 +217,7 @@ int main(int argc, char** argv) {
         ring[k]->setUniforms(uniformStructure);
       }
       auto at = [&](int k) -> rthost::Renderer& { return k == 0 ? renderer : *ring[k]; };
-      for (int k = 0; k < inFlight; k++) { at(k).setParam("trace_blocks_per_cu", 4); at(k).setParam("output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); }
+      for (int k = 0; k < inFlight; k++) { at(k).setParam("output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); }
       std::vector<char> pending(inFlight, 0);
       uint64_t rays = 0; int collected = 0;
       const void* px = nullptr;

@@ -133,9 +133,10 @@ int rt_build_blas(rt_ctx* ctx, int mesh);
 
 /* createInstance + createTLAS (src/main.cpp:538-793; called :1818-1835 with update=false and every
  * frame :2848-2861 with update=true).  update!=0 keeps the TLAS topology and refits boxes (Vulkan
- * UPDATE mode, src=dst); it requires the same instance count as the last build.  Waits for THIS context's pending frame
- * (the records it reads are rewritten), then returns without waiting for the device: the records travel on the
- * context's stream and the next frame is ordered behind them (the reference blocks on a fence here, src/main.cpp:772-778). */
+ * UPDATE mode, src=dst); it requires the same instance count as the last build.  Never waits for the frame in flight: the
+ * instance records and TLAS nodes are double-buffered, the new set travels on the context's stream (pinned staging) and
+ * the next frame is ordered behind it; only the frame before the last is waited for, if it is still running (the reference
+ * allocates buffers and blocks on a fence here every frame, src/main.cpp:672-696, 752-778). */
 int rt_set_instances(rt_ctx* ctx, const rt_instance* instances, int n, int update);
 
 /* ---- MTL materials and a per-instance type table -------------------------------------------------

@@ -192,9 +192,6 @@ class Renderer {
   explicit Renderer(int device = 0) {
     int r = rt_create(&ctx_, device);
     if (r) throwExceptionRtAPI(r, "rt_create", nullptr);
-    // trace() below is the blocking one-frame-at-a-time path: a frame that has the GPU to itself is latency-bound and
-    // runs ~8 % faster with 6 workgroups per CU; the library default (4) is tuned for several frames in flight
-    check(rt_set_param(ctx_, "trace_blocks_per_cu", 6), "rt_set_param");
   }
   // one more frame in flight on the same GPU: shares `scene`'s geometry, BLAS and cube map (rt_create_frame_slot)
   explicit Renderer(Renderer& scene) {

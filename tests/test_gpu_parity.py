@@ -278,12 +278,15 @@ def test_frames_in_flight_async_entry_points(ctx):
                 c.trace_async(W, H)
             with pytest.raises(RtError):
                 ring[0].trace_async(W, H)     # one pending frame per context
-            with pytest.raises(RtError):
-                ring[0].set_instances(sp.instances, update=True)   # the scene of a pending frame is not touched
+            # rt_set_instances never disturbs the frame in flight: the records are double-buffered, the pending frame keeps
+            # the transforms it was submitted with (the reference would block on the frame's fence here, src/main.cpp:772-778)
+            moved_anim = host.SceneAnimation(); moved_anim.animate(1.1)
+            ring[0].set_instances(moved_anim.instances((0, 1)), update=True)
             for c in ring:
                 img, st = c.trace_wait()
                 assert np.array_equal(img, ref)
                 assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (st_ref.rays_primary, st_ref.rays_secondary, st_ref.rays_shadow)
+            ring[0].set_instances(sp.instances, update=True)       # back for the next round
         # 8-bit surface-format output (src/main.cpp:1899): clamp, x255, round — through both the blocking and the async entry
         try:
             ctx.set_param("output_rgba8", 1)
@@ -975,3 +978,4 @@ def test_row_n4_mtl_materials_and_instance_types(ctx):
             c2.set_instance_types([0, 3])
     finally:
         c2.close()
+

@@ -418,12 +418,31 @@ constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both
 constexpr int STACK2_LDS = RT_STACK2_LDS;
 constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 
+// experiment builds (-DRT_EXP_PHASE_SEL=k): diag = (times region k ran, wave cycles spent in it, wave cycles); regions:
+// 1 leaf, 2 leave-instance, 3 enter-instance, 4 finish/flush, 5 refill
+#ifdef RT_EXP_PHASE_SEL
+#define PH_BEGIN(k) uint64_t ph_b##k = 0; if (COUNT && RT_EXP_PHASE_SEL == k) ph_b##k = __builtin_readcyclecounter();
+#define PH_END(k) if (COUNT && RT_EXP_PHASE_SEL == k && lane == 0) { diag_iters++; diag_busy += __builtin_readcyclecounter() - ph_b##k; }
+#else
+#define PH_BEGIN(k)
+#define PH_END(k)
+#endif
+
 template <int MODE, bool ANY, bool COUNT, bool WIDE>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
+  // BVH nodes staged through LDS: the first n_hot entries of the node array are the top levels of every BLAS (breadth-first
+  // over all meshes, rt_api link_blas) — the nodes nearly every ray visits.  A visit to one of them is two ds_read_b128
+  // instead of two divergent 16-byte requests to the CU's vector-memory address unit, which is what bounds this kernel
+  // (about one such lane request per cycle and CU: profiles/r02_*).
+  __shared__ uint4 s_hot[(WIDE || HOT_NODES == 0) ? 1 : HOT_NODES * 2];
+  // Instance records staged through LDS: what "enter the instance" reads (world->object rows, dequantisation, root, mask)
+  // for the first LDS_INSTANCES instances, 80 bytes each.  That phase runs for a quarter of the lanes at a time and was
+  // spending ~1200 cycles per pass on the global-memory latency of these few, shared records.
+  __shared__ float4 s_inst[LDS_INSTANCES ? LDS_INSTANCES : 1][5];
   // Grid sizing on the device: the launch always has the full persistent grid, but a queue that holds only a
   // few rays per lane runs faster on fewer, less contended waves that refill (every ray costs ~25-40 dependent
   // trips, and a trip is quickest with 1-2 waves per SIMD) — surplus blocks leave at once.
@@ -436,6 +455,20 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     if (want < a.min_blocks) want = a.min_blocks;
     if (blockIdx.x >= want) return;
   }
+  const uint32_t n_hot = (WIDE || HOT_NODES == 0) ? 0u : a.sc.n_hot;
+  if (!WIDE && HOT_NODES != 0) {
+    const uint4* src = reinterpret_cast<const uint4*>(a.sc.blas_nodes);
+    for (uint32_t i = threadIdx.x; i < n_hot * 2u; i += 256u) s_hot[i] = src[i];
+  }
+  const int n_lds_inst = a.sc.n_inst < LDS_INSTANCES ? a.sc.n_inst : LDS_INSTANCES;
+  if ((int)threadIdx.x < n_lds_inst) {
+    const InstanceDev* I = a.sc.inst + threadIdx.x;
+    const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+    s_inst[threadIdx.x][0] = mp[0]; s_inst[threadIdx.x][1] = mp[1]; s_inst[threadIdx.x][2] = mp[2];
+    s_inst[threadIdx.x][3] = make_float4(I->q_lo[0], I->q_lo[1], I->q_lo[2], __int_as_float(I->blas_root));
+    s_inst[threadIdx.x][4] = make_float4(I->q_scale[0], I->q_scale[1], I->q_scale[2], __uint_as_float(I->mask));
+  }
+  __syncthreads();
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   int* const stk = &s_stack[wave][0][lane];                 // entry e at stk[e * 64]
   int32_t* const ovf = a.ovf_stack + (size_t)(blockIdx.x * 256u + threadIdx.x) * a.sc.ovf_stride;
@@ -503,6 +536,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   // BLAS nodes, then the TLAS nodes (WIDE: the 64-byte 4-ary records with the same numbering)
   const char* const node_bytes = WIDE ? reinterpret_cast<const char*>(a.sc.wide_nodes) : reinterpret_cast<const char*>(a.sc.blas_nodes);
 
+#if defined(RT_EXP_EXTRA_LOADS) || defined(RT_EXP_EXTRA_VALU)
+  uint32_t exp_acc = 0; float exp_f[4] = {0.5f, 0.25f, 0.125f, 0.75f};
+#endif
   auto push = [&](int v) {
     if (sp < STACK2_LDS) stk[sp * 64] = v;
     else *reinterpret_cast<volatile int32_t*>(ovf + (sp - STACK2_LDS)) = v;
@@ -516,6 +552,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
 
   for (;;) {
     // ---- (A) refill
+    PH_BEGIN(5)
     const uint64_t need_mask = __ballot(need);
     const uint32_t n_need = (uint32_t)__builtin_popcountll(need_mask);
     if (n_need >= REFILL_MIN || n_need == 64u) {
@@ -541,6 +578,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         chunk_pos += n_need < avail ? n_need : avail;
       } else if (n_need == 64u) { flush(); break; }   // queue drained and every lane idle
     }
+    PH_END(5)
     const uint32_t live = 64u - (uint32_t)__builtin_popcountll(__ballot(need));
     const uint32_t keep_going = (live * RT_KEEP_NUM + 7u) >> 3;   // share of the live lanes that must still be interior
 
@@ -585,8 +623,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         return;
       }
       if (cur >= 0) {   // idle lanes hold REF_DONE
-        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
-        const uint4 Q0 = np[0], Q1 = np[1];
+        uint4 Q0, Q1;
+        if ((uint32_t)cur < n_hot) { Q0 = s_hot[2 * cur]; Q1 = s_hot[2 * cur + 1]; }
+        else {
+          const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
+          Q0 = np[0]; Q1 = np[1];
+        }
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
@@ -609,8 +651,23 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     lds_vint* const stk_lds = (lds_vint*)stk;
     auto fast_step = [&]() {
       if (cur >= 0) {
-        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));
-        const uint4 Q0 = np[0], Q1 = np[1];
+        uint4 Q0, Q1;
+        if ((uint32_t)cur < n_hot) { Q0 = s_hot[2 * cur]; Q1 = s_hot[2 * cur + 1]; }
+        else {
+          const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));
+          Q0 = np[0]; Q1 = np[1];
+        }
+#ifdef RT_EXP_EXTRA_LOADS   // sensitivity build: every visit also fetches the neighbouring node (results unused but kept alive)
+        {
+          const uint4* xp = reinterpret_cast<const uint4*>(node_bytes + (((uint32_t)cur ^ 1u) << 5));
+          const uint4 X0 = xp[0], X1 = xp[1];
+          exp_acc ^= X0.x ^ X0.w ^ X1.y ^ X1.w;
+        }
+#endif
+#ifdef RT_EXP_EXTRA_VALU    // sensitivity build: RT_EXP_EXTRA_VALU independent fmas per visit
+#pragma unroll
+        for (int e = 0; e < RT_EXP_EXTRA_VALU; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(exp_f[e & 3]));
+#endif
         // volatile: the read has to be issued here, under the node fetch, not sunk into a branch after the box tests
         const int top = stk_lds[(sp - 1) * 64];
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
@@ -633,12 +690,15 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     for (;;) {
       const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(cur >= 0));
       if (n_int == 0 || n_int < keep_going) break;
-#ifndef RT_EXP_PHASE_DIAG
+#if !defined(RT_EXP_PHASE_DIAG) && !defined(RT_EXP_DEEP_DIAG) && !defined(RT_EXP_PHASE_SEL)
       if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
 #endif
       // fast visits need every stack they touch inside the LDS rows: sp - 1 >= 0 always holds for a live ray, and
       // UNROLL pushes must fit below row STACK2_LDS
       const bool deep = cur >= 0 && sp + UNROLL > STACK2_LDS;
+#ifdef RT_EXP_DEEP_DIAG   // experiment: diag = (interior loop votes, votes that took the generic deep-stack path, wave cycles)
+      if (COUNT && lane == 0) { diag_iters++; diag_busy += __ballot(deep) != 0 ? 1u : 0u; }
+#endif
       if (!WIDE && __ballot(deep) == 0) {
 #pragma unroll
         for (int r = 0; r < UNROLL; r++) fast_step();
@@ -654,6 +714,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     // ---- (C) the rarer bodies, each run once for all lanes that wait at them.  They are chained (leaf, then
     // leave-instance, then enter-instance) so that a lane can finish a leaf, leave its instance and enter the
     // next one in the same pass instead of waiting a whole pass for each step.
+    PH_BEGIN(1)
     if (cur < 0 && cur > REF_MARK && cur_inst >= 0) {
       // BLAS leaf: Moller-Trumbore on 48-byte packets
       const uint32_t ref = (uint32_t)(~cur);
@@ -673,6 +734,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
       else pop();
     }
+    PH_END(1)
+    PH_BEGIN(2)
     if (cur == REF_MARK) {
       // leave the instance: back to the TLAS.  The world-space ray space is needed again only if the next entry is
       // an interior TLAS node (a TLAS leaf sets up its own space, and the bottom sentinel ends the ray)
@@ -680,27 +743,38 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       pop();
       if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
     }
+    PH_END(2)
+    PH_BEGIN(3)
     if (cur < 0 && cur > REF_MARK && cur_inst < 0) {
       // TLAS leaf: enter the instance (ray -> object space, t preserved)
       const int ii = ~cur;
-      const InstanceDev* I = a.sc.inst + ii;
-      if ((I->mask & 0xFFu) == 0u) {
+      float4 m0, m1, m2, ql, qsc;   // w2o rows, (q_lo, root), (q_scale, mask)
+      if (ii < n_lds_inst) { m0 = s_inst[ii][0]; m1 = s_inst[ii][1]; m2 = s_inst[ii][2]; ql = s_inst[ii][3]; qsc = s_inst[ii][4]; }
+      else {
+        const InstanceDev* I = a.sc.inst + ii;
+        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+        m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
+        ql = make_float4(I->q_lo[0], I->q_lo[1], I->q_lo[2], __int_as_float(I->blas_root));
+        qsc = make_float4(I->q_scale[0], I->q_scale[1], I->q_scale[2], __uint_as_float(I->mask));
+      }
+      if ((__float_as_uint(qsc.w) & 0xFFu) == 0u) {
         pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
         if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
       } else {
         float m[12];
-        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
-        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
         m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
         m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
         co = xform_point(m, wo); cd = xform_vec(m, wd);
-        quant_space(co, cd, I->q_lo, I->q_scale, qs, qb, rot);
+        const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
+        quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
         push(REF_MARK);
-        cur_inst = ii; cur = I->blas_root;
+        cur_inst = ii; cur = __float_as_int(ql.w);
       }
     }
 
+    PH_END(3)
     // ---- (D) finished rays: append the result to the wave's LDS out-list
+    PH_BEGIN(4)
     const bool fin = !need && cur == REF_DONE;
     const uint64_t fin_mask = __ballot(fin);
     if (fin_mask != 0) {
@@ -719,7 +793,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       }
       out_count += n_fin;
     }
+    PH_END(4)
   }
+#if defined(RT_EXP_EXTRA_LOADS) || defined(RT_EXP_EXTRA_VALU)
+  if (exp_acc == 0x9E3779B9u && exp_f[0] + exp_f[1] + exp_f[2] + exp_f[3] == 12345.0f) a.counters[CNT_FAULT] = 2u;   // keeps the extra work alive
+#endif
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);

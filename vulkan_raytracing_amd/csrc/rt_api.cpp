@@ -43,7 +43,8 @@ struct Mesh {
   float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
   std::vector<TriPacket> tris;
   int levels = 0;                 // interior levels of the BVH2 (bounds the traversal stack)
-  int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays
+  int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays (before the hot-node reordering)
+  int32_t root = 0;                        // index of the mesh's root node in the linked quantized array
   uint32_t tri_base = 0;
 };
 
@@ -70,7 +71,7 @@ struct Scene {
   uint32_t* d_idx = nullptr;
   std::vector<Mesh> meshes;
   bool blas_linked = false;
-  // linked acceleration structures: BLAS part [0, n_blas*), then MAX_SLOTS TLAS regions of tlas_cap entries each
+  // linked acceleration structures: BLAS part [0, n_blas*), then 2 * MAX_SLOTS TLAS regions (two per slot) of tlas_cap entries each
   std::vector<BvhNodeQ> h_blasq;
   BvhNodeQ* d_blas_nodes = nullptr;
   std::vector<Bvh4Node> h_blas4;
@@ -79,6 +80,7 @@ struct Scene {
   WideNodeQ* d_wide = nullptr;         // variant 2, same numbering as d_blas_nodes
   float4* d_tris = nullptr;
   size_t n_blas_nodes = 0, n_blas4 = 0, n_tris = 0;
+  uint32_t n_hot = 0;                  // leading nodes of d_blas_nodes the traversal kernels keep in LDS (<= HOT_NODES)
   uint32_t tlas_cap = 1024;            // TLAS nodes per slot (grows when a sole owner needs more)
   bool arrays_ready = false;           // device node arrays allocated for (n_blas*, tlas_cap, variant)
   int variant = 0;                     // traversal variant the arrays were linked for
@@ -109,17 +111,23 @@ struct rt_ctx {
   BuiltBvh tlas;
   Bvh4 tlas4;
   bool tlas_valid = false;
-  InstanceDev* d_inst = nullptr;
-  size_t cap_inst = 0;
+  // instance records and TLAS nodes are double-buffered (parity): the records of the next frame are written while the
+  // frame enqueued before still reads its own, so a per-frame TLAS update never waits for the device
+  InstanceDev* d_inst[2] = {nullptr, nullptr};
+  size_t cap_inst[2] = {0, 0};
+  int parity = 0;
+  hipEvent_t ev_frame[2] = {nullptr, nullptr};   // end of the last frame that read the buffers of that parity
+  bool ev_frame_valid[2] = {false, false};
   float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
   uint32_t ovf_stride = STACK_OVF, ovf_alloc_stride = 0;
   int ovf_alloc_blocks = 0;
   // per-frame TLAS update without a host stall: records are assembled in pinned memory and copied on the context's stream;
   // a frame on another stream waits for ev_upload on the device
-  char* h_stage = nullptr;
-  size_t stage_bytes = 0;
-  hipEvent_t ev_upload = nullptr;
-  bool upload_pending = false;
+  char* h_stage[2] = {nullptr, nullptr};
+  size_t stage_bytes[2] = {0, 0};
+  hipEvent_t ev_upload[2] = {nullptr, nullptr};   // the copies from the staging buffer of that parity are done
+  bool upload_inflight[2] = {false, false};
+  bool upload_pending = false;                    // the current parity's copies have not been waited for by a frame yet
 
   // uniforms (binding 1)
   UniformsDev uni{};
@@ -138,6 +146,7 @@ struct rt_ctx {
   uint32_t* d_counters = nullptr;
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
+  bool grid_user_set = false;      // "trace_blocks_per_cu" was set explicitly: keep it
   int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped at rt_create so that MAX_TAILS_IN_FLIGHT of them are always co-resident
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
   unsigned long long* h_stats = nullptr;   // pinned, device-visible StatSlot block written by k_resolve
@@ -278,11 +287,45 @@ int link_blas(rt_ctx* c) {
     m.levels = bvh2_levels(m.qnodes.data(), m.qnodes.size(), 0);
     if (m.levels < 0) return fail(c, RT_ERR_DEVICE, "BLAS builder produced a node graph that is not a tree");
   }
+  // Hot-node order: the kernels keep the first HOT_NODES entries of the node array in LDS, so the nodes every ray meets —
+  // the top levels of every BLAS — are moved to the front: a breadth-first walk over all meshes at once (roots first, then
+  // their children, ...) names the first HOT_NODES interior nodes; everything below keeps its builder order (Morton order
+  // for the device LBVH: good cache locality in the lower levels).  Roots and links are rewritten; any valid numbering
+  // gives the same hits.
+  {
+    std::vector<int32_t> hot;              // old indices in breadth-first order
+    hot.reserve(HOT_NODES);
+    std::vector<int32_t> frontier, next;
+    for (auto& m : S->meshes) if (m.built && !m.qnodes.empty()) frontier.push_back(m.node_base);
+    while (!frontier.empty() && hot.size() < (size_t)HOT_NODES) {
+      next.clear();
+      for (int32_t n : frontier) {
+        if (hot.size() >= (size_t)HOT_NODES) break;
+        hot.push_back(n);
+        const BvhNodeQ& q = nodes[n];
+        if (q.child0 >= 0) next.push_back(q.child0);
+        if (q.child1 >= 0 && q.child1 != q.child0) next.push_back(q.child1);
+      }
+      frontier.swap(next);
+    }
+    std::vector<int32_t> new_of(nn, -1);
+    for (size_t k = 0; k < hot.size(); k++) new_of[hot[k]] = (int32_t)k;
+    int32_t at = (int32_t)hot.size();
+    for (size_t i = 0; i < nn; i++) if (new_of[i] < 0) new_of[i] = at++;
+    std::vector<BvhNodeQ> moved(nn);
+    for (size_t i = 0; i < nn; i++) {
+      BvhNodeQ q = nodes[i];
+      if (q.child0 >= 0) q.child0 = new_of[q.child0];
+      if (q.child1 >= 0) q.child1 = new_of[q.child1];
+      moved[new_of[i]] = q;
+    }
+    nodes.swap(moved);
+    for (auto& m : S->meshes) if (m.built && !m.qnodes.empty()) m.root = new_of[m.node_base]; else m.root = m.node_base;
+    S->n_hot = (uint32_t)hot.size();
+  }
   S->variant = c->cfg.variant;
   std::vector<WideNodeQ> wide(S->variant == 2 ? nn : 0);   // only the variant that walks them pays for them
-  if (S->variant == 2)
-    for (auto& m : S->meshes)
-      if (m.built && !m.qnodes.empty()) widen_bvh2(&nodes[m.node_base], m.qnodes.size(), m.node_base, &wide[m.node_base]);
+  if (S->variant == 2 && nn) widen_bvh2(nodes.data(), nn, 0, wide.data());
   S->h_wide.swap(wide);
   S->h_blas4.swap(nodes4); S->n_blas4 = nn4;
   S->h_blasq.swap(nodes);
@@ -298,7 +341,7 @@ int link_blas(rt_ctx* c) {
 
 int alloc_scene_arrays(rt_ctx* c) {
   Scene* S = c->scene;
-  const size_t regions = (size_t)MAX_SLOTS * S->tlas_cap;
+  const size_t regions = (size_t)2 * MAX_SLOTS * S->tlas_cap;
   if (S->d_blas_nodes) { HIP_TRY(c, hipFree(S->d_blas_nodes)); S->d_blas_nodes = nullptr; }
   if (S->d_nodes4) { HIP_TRY(c, hipFree(S->d_nodes4)); S->d_nodes4 = nullptr; }
   if (S->d_wide) { HIP_TRY(c, hipFree(S->d_wide)); S->d_wide = nullptr; }
@@ -317,8 +360,8 @@ int alloc_scene_arrays(rt_ctx* c) {
 }
 
 // first node of this slot's TLAS region in the quantized / wide arrays and in the BVH4 array
-inline size_t tlas_base(const rt_ctx* c) { return c->scene->n_blas_nodes + (size_t)c->slot * c->scene->tlas_cap; }
-inline size_t tlas_base4(const rt_ctx* c) { return c->scene->n_blas4 + (size_t)c->slot * c->scene->tlas_cap; }
+inline size_t tlas_base(const rt_ctx* c) { return c->scene->n_blas_nodes + (size_t)(2 * c->slot + c->parity) * c->scene->tlas_cap; }
+inline size_t tlas_base4(const rt_ctx* c) { return c->scene->n_blas4 + (size_t)(2 * c->slot + c->parity) * c->scene->tlas_cap; }
 
 // Instance records and this slot's TLAS nodes go to the device WITHOUT stalling the host: they are assembled in pinned
 // memory and copied on the context's stream; ev_upload orders frames on other streams behind the copies.  (The reference
@@ -337,11 +380,12 @@ int upload_instances(rt_ctx* c, const std::vector<InstanceDev>& inst_dev) {
     S->tlas_cap = (uint32_t)((need + 1023) & ~(size_t)1023);
     int r = alloc_scene_arrays(c); if (r) return r;
   }
-  if (n > c->cap_inst) {
-    if (c->d_inst) HIP_TRY(c, hipFree(c->d_inst));
-    c->d_inst = nullptr; c->cap_inst = 0;
-    HIP_TRY(c, hipMalloc((void**)&c->d_inst, n * sizeof(InstanceDev)));
-    c->cap_inst = n;
+  const int par = c->parity;
+  if (n > c->cap_inst[par]) {
+    if (c->d_inst[par]) HIP_TRY(c, hipFree(c->d_inst[par]));
+    c->d_inst[par] = nullptr; c->cap_inst[par] = 0;
+    HIP_TRY(c, hipMalloc((void**)&c->d_inst[par], n * sizeof(InstanceDev)));
+    c->cap_inst[par] = n;
   }
   const size_t base = tlas_base(c), base4 = tlas_base4(c);
   for (auto& nd : tq) {   // interior links are relative to the TLAS: rebase them to this slot's region
@@ -360,24 +404,24 @@ int upload_instances(rt_ctx* c, const std::vector<InstanceDev>& inst_dev) {
   // pinned staging: [instances][quantized TLAS][BVH4 TLAS][wide TLAS]
   const size_t b_inst = n * sizeof(InstanceDev), b_q = tq.size() * sizeof(BvhNodeQ), b_4 = t4.size() * sizeof(Bvh4Node), b_w = tw.size() * sizeof(WideNodeQ);
   const size_t total = b_inst + b_q + b_4 + b_w;
-  if (total > c->stage_bytes) {
-    if (c->h_stage) HIP_TRY(c, hipHostFree(c->h_stage));
-    c->h_stage = nullptr; c->stage_bytes = 0;
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, total + 4096, hipHostMallocDefault));
-    c->stage_bytes = total + 4096;
+  if (total > c->stage_bytes[par]) {
+    if (c->h_stage[par]) HIP_TRY(c, hipHostFree(c->h_stage[par]));
+    c->h_stage[par] = nullptr; c->stage_bytes[par] = 0;
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage[par], total + 4096, hipHostMallocDefault));
+    c->stage_bytes[par] = total + 4096;
   }
-  if (!c->ev_upload) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming));
-  char* st = c->h_stage;
+  if (!c->ev_upload[par]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_upload[par], hipEventDisableTiming));
+  char* st = c->h_stage[par];
   memcpy(st, inst_dev.data(), b_inst);
   memcpy(st + b_inst, tq.data(), b_q);
   if (b_4) memcpy(st + b_inst + b_q, t4.data(), b_4);
   if (b_w) memcpy(st + b_inst + b_q + b_4, tw.data(), b_w);
-  HIP_TRY(c, hipMemcpyAsync(c->d_inst, st, b_inst, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(c, hipMemcpyAsync(c->d_inst[par], st, b_inst, hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipMemcpyAsync(S->d_blas_nodes + base, st + b_inst, b_q, hipMemcpyHostToDevice, c->stream));
   if (b_4) HIP_TRY(c, hipMemcpyAsync(S->d_nodes4 + base4, st + b_inst + b_q, b_4, hipMemcpyHostToDevice, c->stream));
   if (b_w) HIP_TRY(c, hipMemcpyAsync(S->d_wide + base, st + b_inst + b_q + b_4, b_w, hipMemcpyHostToDevice, c->stream));
-  HIP_TRY(c, hipEventRecord(c->ev_upload, c->stream));
-  c->upload_pending = true;
+  HIP_TRY(c, hipEventRecord(c->ev_upload[par], c->stream));
+  c->upload_pending = true; c->upload_inflight[par] = true;
   return RT_OK;
 }
 
@@ -386,10 +430,11 @@ SceneDev scene_dev(const rt_ctx* c) {
   SceneDev s{};
   s.nodes4 = S->d_nodes4; s.tlas_root4 = (int)tlas_base4(c);
   s.wide_nodes = S->d_wide; s.ovf_stride = c->ovf_stride;
-  s.blas_nodes = S->d_blas_nodes; s.tlas_root = (int)tlas_base(c); s.tris = S->d_tris; s.inst = c->d_inst;
+  s.blas_nodes = S->d_blas_nodes; s.tlas_root = (int)tlas_base(c); s.tris = S->d_tris; s.inst = c->d_inst[c->parity];
   s.verts = S->d_verts; s.idx = S->d_idx; s.sky = S->d_sky; s.n_inst = (int)c->h_inst.size();
   s.sky_w = S->sky_w; s.sky_h = S->sky_h;
   s.materials = S->d_materials; s.prim_material = S->d_prim_material; s.n_materials = S->n_materials;
+  s.n_hot = S->n_hot;
   for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
   return s;
 }
@@ -408,7 +453,9 @@ int quiesce_scene(rt_ctx* c) {
   for (rt_ctx* m : c->scene->members) {
     if (m->async_pending) return fail(c, RT_ERR_NOT_READY, "a frame slot of this scene has a frame pending (rt_trace_async): collect it with rt_trace_wait first");
     if (m->frame_pending) { int r = collect_stats(m); if (r) { if (m != c) c->error = m->error; return r; } }
-    if (m->upload_pending) { HIP_TRY(c, hipEventSynchronize(m->ev_upload)); m->upload_pending = false; }
+    for (int k = 0; k < 2; k++)
+      if (m->upload_inflight[k]) { HIP_TRY(c, hipEventSynchronize(m->ev_upload[k])); m->upload_inflight[k] = false; }
+    m->upload_pending = false;
   }
   return RT_OK;
 }
@@ -502,7 +549,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
   c->last_empty = rows == 0;
   // the instance records / TLAS nodes of this slot were copied on the context's stream: a frame on another stream waits on the device
-  if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload, 0));
+  if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload[c->parity], 0));
   if (rows == 0) { HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s)); return RT_OK; }
   {
     Span frame_span(c, CAT_FRAME, s);
@@ -538,6 +585,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     { Span sp(c, CAT_RESOLVE, s); launch_resolve(f, u, s); }
   }
   HIP_TRY(c, hipGetLastError());
+  // the instance records / TLAS nodes of this parity are in use until here
+  if (!c->ev_frame[c->parity]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_frame[c->parity], hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->ev_frame[c->parity], s));
+  c->ev_frame_valid[c->parity] = true;
   return RT_OK;
 }
 
@@ -611,6 +662,16 @@ extern "C" {
 
 int rt_abi_version(void) { return 4; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials
 
+// Persistent traversal grid, workgroups per CU.  A lone context renders one frame at a time: the kernels are latency-bound and
+// 5 workgroups per CU (all the LDS admits) are fastest (cfg3: 1.00 ms vs 1.03 at 4, 1.28 at 2).  With several frame slots the
+// frames overlap, and a traversal kernel that parks fewer workgroups leaves registers and wave slots to the other frames'
+// kernels: 3 per CU (cfg3 with 4 slots: 0.642 ms per frame vs 0.667 at 4; cfg4 -1 %, limbs mesh -2 %, cfg5 +1 %).
+static void size_traversal_grids(Scene* S) {
+  const int per_cu = S->members.size() >= 3 ? 3 : 5;
+  for (rt_ctx* m : S->members)
+    if (!m->grid_user_set) m->cfg.trace_blocks = m->n_cu * per_cu;
+}
+
 static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (!out_ctx) return fail(nullptr, RT_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
   *out_ctx = nullptr;
@@ -655,6 +716,9 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->slot = slot;
   c->scene->slot_mask |= 1u << slot;
   c->scene->members.push_back(c);
+  if (getenv("RT_TRACE_BLOCKS_PER_CU")) c->grid_user_set = true;
+  if (parent) c->grid_user_set = parent->grid_user_set;
+  size_traversal_grids(c->scene);
   *out_ctx = c;
   return RT_OK;
 }
@@ -671,19 +735,20 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_inst, c->d_out_own, c->d_counters, c->d_ovf,
+  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
   if (c->h_out_pinned) hipHostFree(c->h_out_pinned);
   if (c->h_stats) hipHostFree(c->h_stats);
-  if (c->h_stage) hipHostFree(c->h_stage);
-  if (c->ev_upload) hipEventDestroy(c->ev_upload);
+  for (int k = 0; k < 2; k++) { if (c->h_stage[k]) hipHostFree(c->h_stage[k]); if (c->ev_frame[k]) hipEventDestroy(c->ev_frame[k]); }
+  for (int k = 0; k < 2; k++) if (c->ev_upload[k]) hipEventDestroy(c->ev_upload[k]);
   for (auto e : c->ev_pool) hipEventDestroy(e);
   if (c->stream) hipStreamDestroy(c->stream);
   Scene* S = c->scene;
   S->members.erase(std::remove(S->members.begin(), S->members.end(), c), S->members.end());
   S->slot_mask &= ~(1u << c->slot);
+  size_traversal_grids(S);
   if (S->members.empty()) {   // the last context of a scene takes the shared arrays with it
     void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky, S->d_materials, S->d_prim_material};
     for (void* p : sp) if (p) hipFree(p);
@@ -765,10 +830,13 @@ int rt_build_blas(rt_ctx* c, int mesh) {
 int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!inst || n <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "no instances");
-  { int q = quiesce(c); if (q) return q; }   // this slot's previous frame still reads the records below
   HIP_TRY(c, hipSetDevice(c->device));
   Scene* S = c->scene;
-  if (c->upload_pending) { HIP_TRY(c, hipEventSynchronize(c->ev_upload)); c->upload_pending = false; }   // staging is reused
+  // Double-buffered records: this call fills the set the frame enqueued LAST does not read, so it waits only for the frame
+  // before that one (usually long finished) — a per-frame update never stalls the host on the frame in flight.
+  const int next_parity = c->parity ^ 1;
+  if (c->ev_frame_valid[next_parity]) { HIP_TRY(c, hipEventSynchronize(c->ev_frame[next_parity])); c->ev_frame_valid[next_parity] = false; }
+  if (c->upload_inflight[next_parity]) { HIP_TRY(c, hipEventSynchronize(c->ev_upload[next_parity])); c->upload_inflight[next_parity] = false; }   // its staging buffer is rewritten
   for (int i = 0; i < n; i++) {
     if (inst[i].mesh >= S->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance references an unknown mesh");
     if (!S->meshes[inst[i].mesh].built) return fail(c, RT_ERR_NOT_READY, "instance references a mesh whose BLAS is not built (rt_build_blas)");
@@ -787,7 +855,7 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     const Mesh& m = S->meshes[inst[i].mesh];
     memcpy(d.o2w, inst[i].transform, sizeof(d.o2w));
     invert_affine(d.o2w, d.w2o);
-    d.blas_root = m.node_base;
+    d.blas_root = m.root;
     d.blas_root4 = m.node_base4;
     d.mask = m.range.prim_count ? (inst[i].custom_index_and_mask >> 24) : 0u;   // an empty mesh is never entered
     for (int k = 0; k < 3; k++) { d.q_lo[k] = m.q_lo[k]; d.q_scale[k] = m.q_scale[k]; }
@@ -818,6 +886,7 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   if (1 + c->tlas4.stack_need + 1 + blas_need > STACK4_LDS)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
                     " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
+  c->parity = next_parity;
   int r = upload_instances(c, inst_dev); if (r) return r;
   c->tlas_valid = true;
   return RT_OK;
@@ -943,7 +1012,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "trace_blocks_per_cu") {
     if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
     { int q = quiesce(c); if (q) return q; }   // the spill stacks are re-sized by the next frame (ensure_common)
-    c->cfg.trace_blocks = c->n_cu * value; return RT_OK;
+    c->cfg.trace_blocks = c->n_cu * value; c->grid_user_set = true; return RT_OK;
   }
   if (k == "output_rgba8") {
     if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "output_rgba8 must be 0 or 1");

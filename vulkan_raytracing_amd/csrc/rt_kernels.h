@@ -25,6 +25,7 @@ struct SceneDev {
   const MaterialDev* materials;   // row n4: MTL material table (NULL / n_materials == 0: the reference's hard-coded constants)
   const uint32_t* prim_material;  // material of every triangle of the index buffer (global primitive number = first_index / 3 + gl_PrimitiveID)
   int n_materials;
+  uint32_t n_hot;              // nodes [0, n_hot) of blas_nodes are the hot set (<= HOT_NODES), staged through LDS by k_trace
 };
 
 struct FrameDev {
