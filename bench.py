@@ -47,6 +47,11 @@ RAY_BYTES, HIT_BYTES = 32, 20
 ANIM_DT = 1.0 / 60.0    # fixed time step of the animated leg (the reference uses the wall clock, src/main.cpp:2798-2800)
 
 
+def mark(msg):
+    if os.environ.get("RT_BENCH_TRACE"):
+        print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
 def kernels_sha16():
     """identifies the kernel sources a profile was taken with (profiles/*.json carry the same field)"""
     h = hashlib.sha256()
@@ -282,7 +287,9 @@ def main():
     for _ in range(P):
         rig.step()
     rig.sync()
+    mark("set-up frames done")
     dt = rig.timed(args.steps, args.warmup, animate=args.animate)
+    mark("timed region done")
     st = ctx.stats()        # counters of slot 0's last frame + MEAN event times over all its timed frames (every P-th step)
     last_frame = None
     if args.save_image and rank == 0 and rig.frames[(rig.counter - 1) % P] is not None:
@@ -305,6 +312,7 @@ def main():
         if collective:
             dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         anim_ms = float(ta.item()) / args.steps * 1e3
+        mark("animated region done")
         # back to the t = 0 scene for the measurements below
         for c in rig.ctxs:
             c.set_instances(wl.instances)
@@ -342,10 +350,12 @@ def main():
             ctx.trace_shard(W, H, rig.band, rank, n, rig.shards[0].data_ptr(), rig.shards[0].numel() * 4, rig.streams[0].cuda_stream)
             iso.append(ctx.stats())
         iso_ms = sorted(x.ms_trace_closest for x in iso)[len(iso) // 2]
+        mark("isolated frames done")
         ctx.set_timing(False)
         # (2) mean node visits / triangle tests per ray from the instrumented build of the same kernel over the
         # full frame (exact for n == 1; for n > 1 rank 0's bands are an interleaved sample of it)
         _, cst = ctx.trace(W, H, counting=True)
+        mark("counting frame done")
         mean_nodes = cst.node_visits / max(1, cst.closest_rays)
         mean_tris = cst.tri_tests / max(1, cst.closest_rays)
         # rays that entered the k_trace<closest> launches: survivors of the TLAS-root test, plus the secondary rays unless
@@ -402,6 +412,7 @@ def main():
                 fh.write(b"PF4\n%d %d\n-1.0\n" % (W, H))
                 fh.write(img[::-1].astype("<f4").tobytes())
     rig.close()
+    mark("rig closed")
     if rank == 0 and not args.no_extras:
         # one frame at a time on a context of its own (no frame slots: the library then sizes its persistent grids for a lone
         # frame), wall clock of enqueue + wait, rank 0's shard
@@ -420,6 +431,7 @@ def main():
             lone.synchronize()
         result["ms_per_frame_single"] = (time.perf_counter() - t0) / 20 * 1e3
         lone.close()
+        mark("lone context done")
     if rank == 0:
         # ---- the same workload on the other stand-in mesh (one GPU only) -------------------------------------------------
         if n == 1 and not args.no_extras and not collective and args.workload in ("cfg3", "cfg5") and not os.path.exists(os.path.join(res, "armadillo.obj")):
@@ -437,6 +449,7 @@ def main():
                                     "mean_node_visits_per_ray": c2.node_visits / max(1, c2.closest_rays), "mean_tri_tests_per_ray": c2.tri_tests / max(1, c2.closest_rays),
                                     "mean_node_visits_per_shadow_ray": c2.node_visits_shadow / max(1, c2.rays_shadow)}
             rig2.close()
+            mark("other mesh done")
         if n == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(wl)
         else:

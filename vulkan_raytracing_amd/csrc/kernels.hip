@@ -1313,6 +1313,9 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
       f.out[p] = px;
     }
   }
+  // The next frame of this context finds its counters zeroed (no memset dispatch per frame): it uses the other block.
+  if (f.counters_next)
+    for (uint32_t i = p; i < (uint32_t)CNT_WORDS; i += gridDim.x * blockDim.x) f.counters_next[i] = 0u;
   // This is the last kernel of the frame, so every counter is final: workgroup 0 condenses them into the host-mapped
   // statistics block (rt_device.h StatSlot).
   if (blockIdx.x == 0 && f.stats_out) {

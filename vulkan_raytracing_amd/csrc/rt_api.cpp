@@ -143,7 +143,8 @@ struct rt_ctx {
   bool out_rgba8 = false;          // "output_rgba8": frames are stored as 8-bit RGBA (4 bytes per pixel) instead of RGBA32F
   bool async_pending = false;
   int async_w = 0, async_h = 0;
-  uint32_t* d_counters = nullptr;
+  uint32_t* d_counters = nullptr;   // TWO counter blocks: frame k uses block k & 1 and its last kernel zeroes the other one for frame k + 1
+  int cnt_parity = 0;
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
   bool grid_user_set = false;      // "trace_blocks_per_cu" was set explicitly: keep it
@@ -469,7 +470,14 @@ int ready_to_trace(rt_ctx* c) {
 }
 
 int ensure_common(rt_ctx* c) {
-  if (!c->d_counters) HIP_TRY(c, hipMalloc((void**)&c->d_counters, CNT_WORDS * sizeof(uint32_t)));
+  if (!c->d_counters) {
+    HIP_TRY(c, hipMalloc((void**)&c->d_counters, 2 * CNT_WORDS * sizeof(uint32_t)));
+    // zeroed BEFORE any frame can be enqueued on whatever stream: a plain hipMemset of device memory may still be running
+    // when it returns, and the frame's stream is not ordered behind the null stream
+    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, 2 * CNT_WORDS * sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->cnt_parity = 0;
+  }
   if (!c->h_hint) {
     HIP_TRY(c, hipHostMalloc((void**)&c->h_hint, CNT_MAX_BOUNCES * sizeof(uint32_t), hipHostMallocMapped));
     for (int b = 0; b < CNT_MAX_BOUNCES; b++) c->h_hint[b] = 0xFFFFFFFFu;   // unknown: the first frame takes one launch per bounce
@@ -536,7 +544,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   const size_t capacity = shard_cap * N_SHARDS;
   int r = ensure_frame(c, capacity); if (r) return r;
   FrameDev f = c->frame;
-  f.counters = c->d_counters; f.ovf_stack = c->d_ovf; f.out = d_out; f.out_rgba8 = c->out_rgba8 ? 1 : 0; f.hint = c->d_hint; f.stats_out = c->d_stats;
+  // the counters of this frame were zeroed by the previous frame's k_resolve (or at allocation); this frame's k_resolve zeroes the other block
+  f.counters = c->d_counters + (size_t)c->cnt_parity * CNT_WORDS; f.counters_next = c->d_counters + (size_t)(c->cnt_parity ^ 1) * CNT_WORDS;
+  f.ovf_stack = c->d_ovf; f.out = d_out; f.out_rgba8 = c->out_rgba8 ? 1 : 0; f.hint = c->d_hint; f.stats_out = c->d_stats;
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   const SceneDev sc = scene_dev(c);
@@ -550,10 +560,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   c->last_empty = rows == 0;
   // the instance records / TLAS nodes of this slot were copied on the context's stream: a frame on another stream waits on the device
   if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload[c->parity], 0));
-  if (rows == 0) { HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s)); return RT_OK; }
+  if (rows == 0) return RT_OK;   // nothing is launched: both counter blocks stay zero
+  c->cnt_parity ^= 1;
   {
     Span frame_span(c, CAT_FRAME, s);
-    HIP_TRY(c, hipMemsetAsync(c->d_counters, 0, CNT_WORDS * sizeof(uint32_t), s));
     { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
     // either strategy gives the same image); bounces before it run on the full persistent grid
@@ -574,7 +584,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
         uint32_t tails[N_SHARDS * CNT_STRIDE];
-        HIP_TRY(c, hipMemcpyAsync(tails, c->d_counters + cnt_tail((int)b + 1, 0), sizeof(tails), hipMemcpyDeviceToHost, s));
+        HIP_TRY(c, hipMemcpyAsync(tails, f.counters + cnt_tail((int)b + 1, 0), sizeof(tails), hipMemcpyDeviceToHost, s));
         HIP_TRY(c, hipStreamSynchronize(s));
         uint32_t live = 0;
         for (int t = 0; t < N_SHARDS; t++) live += tails[t * CNT_STRIDE];
@@ -1271,6 +1281,10 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipMemcpy(out, d_h, n * sizeof(HitRec), hipMemcpyDeviceToHost));
+  struct Rezero {   // frames expect both counter blocks zeroed, on whatever stream they are enqueued next
+    rt_ctx* c;
+    ~Rezero() { (void)hipMemsetAsync(c->d_counters, 0, 2 * CNT_WORDS * sizeof(uint32_t), c->stream); (void)hipStreamSynchronize(c->stream); c->cnt_parity = 0; }
+  } rezero{c};
   if (stats) {
     uint32_t cnt[CNT_TAILS];
     HIP_TRY(c, hipMemcpy(cnt, c->d_counters, sizeof(cnt), hipMemcpyDeviceToHost));

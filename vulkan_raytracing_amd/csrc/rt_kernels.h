@@ -37,7 +37,8 @@ struct FrameDev {
   float4* sh_d;                //               (L.xyz, sample id bits)
   float4* sh_c;                //               (tmpColor if the light is visible: rgb, material tag bits)
   float4* sample_color;        // per-sample tmpColor (rgb, 1), index = i*(rows*W) + ly*W + x
-  uint32_t* counters;          // rt::CNT_* layout
+  uint32_t* counters;          // rt::CNT_* layout; zero when the frame starts
+  uint32_t* counters_next;     // the context's other counter block: k_resolve (the frame's last kernel) zeroes it for the next frame
   int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread
   unsigned long long* stats_out;   // host-mapped StatSlot block, written by k_resolve (NULL: not wanted)
   uint32_t* hint;              // host-mapped array [CNT_MAX_BOUNCES]: size of every bounce queue, written by k_resolve and
