@@ -76,6 +76,20 @@ def main():
             print("closest-hit traversal: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB per launch -> HBM bytes/launch %.3e (x2 read correction) / %.3e (raw)" % (fetch_kib, write_kib, hi, lo))
     if "--json" in sys.argv:
         json.dump(res, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
+    # profiles/latest_profile.json: what bench.py attaches to its roofline block — only when its tag matches the run
+    if "--latest" in sys.argv:
+        out = sys.argv[sys.argv.index("--latest") + 1]
+        tag = json.loads(os.environ.get("RT_PROFILE_TAG", "{}"))
+        closest = [v for k, v in tr.items() if "k_trace<0, false, false" in k or "k_trace<(int)0, (bool)0, (bool)0" in k]
+        durs = sorted(closest[0]) if closest else []
+        big = [x for x in durs if x >= 0.5 * durs[-1]] if durs else []      # the bounce-0 launches (a context's first frame also launches small later bounces)
+        latest = {"tag": tag, "source": os.environ.get("RT_PROFILE_SOURCE", base),
+                  "k_trace_closest_avg_ms": (sum(big) / len(big) / 1e3) if big else None, "k_trace_closest_launches": len(big),
+                  "hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "hbm_bytes_per_launch_uncorrected": res.get("hbm_bytes_per_launch_uncorrected"),
+                  "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernels serialised by the profiler), read side doubled per MI355X_MICROARCH.md (HBM)",
+                  "limiter": os.environ.get("RT_PROFILE_LIMITER")}
+        json.dump(latest, open(out, "w"), indent=1)
+        print("wrote", out, json.dumps(latest)[:300])
 
 
 if __name__ == "__main__":
