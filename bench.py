@@ -29,12 +29,13 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
-# A 1/N frame shard is latency-bound, so a sharded run keeps 8 frames in flight and gives each of their streams its own
-# hardware queue (HIP maps streams onto 4 by default; read at HIP start-up).  Measured on one GPU, rank 0's shard of an
-# 8-way split: 0.143 ms per frame with 4 frames / 4 queues, 0.124 ms with 8 / 8; a whole frame is 3 % slower with 8 / 8,
-# so a single-GPU run keeps the defaults.
+# A 1/N frame shard is latency-bound (a lone 1/8 shard of cfg3 takes 0.45 ms, 0.16 ms of it the slowest rays of each traversal
+# launch), so a sharded run keeps more frames in flight and gives each of their streams its own hardware queue (HIP maps
+# streams onto 4 by default; read at HIP start-up).  Measured on one GPU (tools/pipeline_cost.py, profiles/r02_shard_ceiling.txt),
+# rank 0's shard of an 8-way split: 0.129 ms per frame with 4 slots / 4 queues, 0.112 with 8 / 8, 0.106-0.108 with 16 / 16
+# (= 5.9-6.2 x the whole frame's 0.64 ms); a whole frame gains nothing from more than 4, so a single-GPU run keeps the defaults.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -219,8 +220,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots per GPU, each with its own stream; the reference keeps swapchainImageCount = minImageCount + 1 frames in "
-                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 on one GPU, 8 when the frame is split over several — one per "
-                         "HIP hardware queue (isolated kernels are latency-bound; frames in flight fill the gaps)")
+                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 up to two GPUs, 8 on four, 16 on eight — the smaller a rank's "
+                         "shard the more latency-bound its kernels, and frames in flight fill the gaps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the animated leg, the single-frame latency and the second mesh (profiling runs)")
     ap.add_argument("--param", action="append", default=[], help="rt_set_param NAME=VALUE on every context (experiments), repeatable")
@@ -270,7 +271,7 @@ def main():
     n = world
     collective = n > 1 or args.force_collective
     assert args.gpus == n, "--gpus must equal the number of launched ranks"
-    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n == 1 else 8)
+    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else (8 if n <= 4 else 16))
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
