@@ -306,6 +306,7 @@ def main():
 
     # ---- the animated loop as a second timed region (every rank takes part: it contains the gather) ----------------------
     anim_ms = None
+    anim_rays = 0.0
     if not args.no_extras and not args.animate:
         ctx.set_timing(False)
         dta = rig.timed(args.steps, max(P, args.warmup), animate=True)
@@ -313,6 +314,11 @@ def main():
         if collective:
             dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         anim_ms = float(ta.item()) / args.steps * 1e3
+        # the animated frames are different frames (the orbiting mesh moves through the view): their own ray count, from the last frame of every slot
+        anim_rays = torch.tensor([float(sum(c.stats().rays_total for c in rig.ctxs)) / P], dtype=torch.float64, device=dev)
+        if collective:
+            dist.all_reduce(anim_rays, op=dist.ReduceOp.SUM)
+        anim_rays = float(anim_rays.item())
         mark("animated region done")
         # back to the t = 0 scene for the measurements below
         for c in rig.ctxs:
@@ -337,6 +343,7 @@ def main():
                   "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "animated_ms_per_step": anim_ms,
+                  "animated_value": (anim_rays / anim_ms / 1e3) if anim_ms else None,   # Mrays/s of the animated loop (mean rays of its last frames)
                   "config": {"workload": wl.describe() + (" [animated loop timed]" if args.animate else ""), "mesh": wl.mesh_label,
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
                              "ray_classes": "value counts every traceRayEXT-equivalent: primary + secondary (bounce) + shadow rays; 'secondary' in the metric string means both",
