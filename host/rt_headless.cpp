@@ -52,7 +52,7 @@ static void writePPM(const std::string& path, const std::vector<float>& rgba, in
 
 int main(int argc, char** argv) {
   int W = 800, H = 600;  // the reference's window size (src/main.cpp:805)
-  int frames = 3, device = 0, inFlight = 1, gpus = 0;
+  int frames = 3, device = 0, inFlight = 1, gpus = 0, blocksPerCu = 0;
   bool rgba8 = false, loopback = false;
   float dt = 1.0f / 60.0f;
   std::string center = CENTER_MESH_OBJ_PATH, orbiting = ORBITING_MESH_OBJ_PATH, skyDir = SKYBOX_TEXTURE_DIR, out = "frame";
@@ -74,6 +74,7 @@ int main(int argc, char** argv) {
     else if (a == "--out") out = next();
     else if (a == "--device") device = atoi(next());
     else if (a == "--gpus") gpus = atoi(next());
+    else if (a == "--blocks-per-cu") blocksPerCu = atoi(next());   // persistent traversal grid (experiments; 0 = the library's choice)
     else if (a == "--loopback") loopback = true;
     else if (a == "--rgba8") rgba8 = true;   // frames come back in the 8-bit surface format the reference presents (src/main.cpp:1899); needs --frames-in-flight > 1
     else if (a == "--frames-in-flight") inFlight = std::max(1, atoi(next()));   // the reference: swapchain image count, src/main.cpp:1203
@@ -217,7 +218,7 @@ int main(int argc, char** argv) {
         ring[k]->setUniforms(uniformStructure);
       }
       auto at = [&](int k) -> rthost::Renderer& { return k == 0 ? renderer : *ring[k]; };
-      for (int k = 0; k < inFlight; k++) { at(k).setParam("output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); }
+      for (int k = 0; k < inFlight; k++) { at(k).setParam("output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); if (blocksPerCu > 0) at(k).setParam("trace_blocks_per_cu", blocksPerCu); }
       std::vector<char> pending(inFlight, 0);
       uint64_t rays = 0; int collected = 0;
       const void* px = nullptr;

@@ -132,7 +132,7 @@ constexpr int Q_SHADOW = CNT_MAX_BOUNCES;      // queue id of the shadow-ray que
 constexpr int N_QUEUES = CNT_MAX_BOUNCES + 1;
 constexpr int TAIL_BLOCKS = 64;                // largest grid of k_tail (rt_api clamps it to the device: tail_grid())
 constexpr int MAX_TAILS_IN_FLIGHT = 16;        // k_tail launches (frame slots) that must be co-resident on one GPU at any time
-constexpr uint32_t TAIL_MAX_RAYS = 65536;      // bounces whose queue was larger in the previous frame get their own full-grid launches
+constexpr uint32_t TAIL_MAX_RAYS = 16384;      // bounces whose queue was larger in the previous frame get their own full-grid launches (k_tail then has at most one ray per lane: a 64-workgroup grid walks 26 k rays in 0.37 ms, the full grid in 0.05)
 enum : int {
   CNT_NODE_VISITS = 0,     // uint64: closest-hit kernel (counting builds only)
   CNT_TRI_TESTS = 2,       // uint64
