@@ -81,6 +81,11 @@ int main(int argc, char** argv) {
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
   }
   try {
+    // More than four frames in flight: give every slot's stream its own hardware queue (HIP maps streams onto 4 by default and
+    // reads this once at start-up, before the first HIP call).  A frame that is being copied to the host does not compute, so
+    // keeping 4 frames COMPUTING takes 5-6 slots: 1920x1080 animated, every frame copied to host memory, measured per frame:
+    // 4 slots / 4 queues 0.98 ms, 6 / 4 0.82, 4 / 8 0.84, 6 / 8 0.73, 8 / 8 0.78.  Never overrides the caller's setting.
+    if (inFlight > 4 && gpus == 0) setenv("GPU_MAX_HW_QUEUES", "8", 0);
     // resources/armadillo.obj is absent from the reference snapshot: fall back to the labelled stand-in
     std::string meshLabel = orbiting;
     if (!std::ifstream(orbiting).good() && orbiting.find("armadillo.obj") != std::string::npos) {

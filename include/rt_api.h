@@ -55,7 +55,13 @@ typedef struct rt_instance {
   uint32_t custom_index_and_mask;   /* instanceCustomIndex:24 (low) | mask:8 (high) */
   uint32_t sbt_offset_and_flags;    /* instanceShaderBindingTableRecordOffset:24 | flags:8 (ignored: the
                                        reference always uses offset 0 / TRIANGLE_FACING_CULL_DISABLE) */
-  uint64_t mesh;                    /* index into rt_mesh_range[] — replaces accelerationStructureReference */
+  uint64_t mesh;                    /* index into rt_mesh_range[] — replaces accelerationStructureReference.
+                                       RULE: the closest-hit stage reads the index/vertex range of THIS mesh.  The reference
+                                       picks the range from instanceCustomIndex instead (src/shader.rchit:52-58: index 0 -> no
+                                       offset, otherwise the orbiting object's offsets), which is the same thing whenever
+                                       customIndex k is given to instances of mesh k, as src/main.cpp:1810-1816 does; an
+                                       instance of mesh 1 created with customIndex 0 would read the wrong triangles there and
+                                       the right ones here.  customIndex still selects the material type (src/shader.rgen:96) */
 } rt_instance;
 
 /* The 104-byte UniformStructure, field for field (src/main.cpp:1847-1866; src/shader.rgen:22-46). */

@@ -705,8 +705,8 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->n_cu = prop.multiProcessorCount;
   c->info = std::string("gfx950 ") + prop.name + " CUs=" + std::to_string(prop.multiProcessorCount);
   if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return fail(nullptr, RT_ERR_DEVICE, "hipStreamCreate failed"); }
-  // persistent grids: ~27 KB of LDS and <= 84 VGPRs per 256-thread block admit 5-6 blocks per CU
-  // (4 measured best with three frames in flight: the other frames' kernels need room; 6 is best for a lone frame)
+  // persistent grids: ~27 KB of LDS and <= 84 VGPRs per 256-thread block admit 5 blocks per CU; size_traversal_grids() below
+  // picks 5 per CU for a lone frame slot and 3 once three or more slots share the GPU (the other frames' kernels need room)
   c->cfg.trace_blocks = c->n_cu * 4;
   c->cfg.shade_blocks = c->n_cu * 8;
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
