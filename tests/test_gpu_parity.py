@@ -979,37 +979,3 @@ def test_row_n4_mtl_materials_and_instance_types(ctx):
     finally:
         c2.close()
 
-
-
-@pytest.mark.parametrize("spp", [1, 4, 5])
-def test_fused_ray_generation_is_result_identical(ctx, spp):
-    """rt_set_param("fused_raygen", 1): bounce 0 generates its rays inside the traversal kernel (no k_raygen, no
-    primary-ray queue).  Same frames, same ray counts — whole frames at a ragged size, band shards of odd heights,
-    sample counts that do not fill a workgroup, a mirror + refractive pair so that later bounces read the records the
-    fused kernel wrote — and the unfused frame equals the oracle's."""
-    import torch
-    arm, _ = host.armadillo_path(RES)
-    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 1, 3, spp, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.4)
-    W, H = 203, 117
-    try:
-        ctx.set_param("fused_raygen", 0)
-        base, st0 = ctx.trace(W, H)
-        ctx.set_param("fused_raygen", 1)
-        for _ in range(2):   # the second frame sizes its grid from the first one's survivor count
-            img, st1 = ctx.trace(W, H)
-            assert np.array_equal(img, base)
-            assert (st0.rays_primary, st0.rays_secondary, st0.rays_shadow) == (st1.rays_primary, st1.rays_secondary, st1.rays_shadow)
-        for band, n in ((8, 3), (5, 2)):
-            rows_max = tiling.max_shard_rows(H, band, n)
-            shards = []
-            for s in range(n):
-                buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
-                ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
-                ctx.synchronize()
-                shards.append(buf.cpu().numpy())
-            assert np.array_equal(tiling.assemble(shards, H, W, band), base)
-    finally:
-        ctx.set_param("fused_raygen", 0)
-    ref, rc = sp.orc.render(W, H)
-    check_image(base, ref)
-    assert (st0.rays_primary, st0.rays_secondary, st0.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))

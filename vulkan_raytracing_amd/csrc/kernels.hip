@@ -300,84 +300,58 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
 // (src/shader.rgen:90-94) is written here and it never touches a queue; the survivors are compacted
 // into bounce queue 0 (shard blockIdx % 8) with a wavefront ballot.  On the headline frame ~80 % of
 // the primary rays end here, which removes their ray/hit records from HBM traffic altogether.
-// What ray generation needs to know about the frame (a subset of FrameDev + UniformsDev, so that the fused traversal kernel
-// does not carry both structures in its arguments).
-struct GenArgs {
-  int width, height, rows, band_rows, n_shards, shard;
-  uint32_t spp, tiles_x, n_tiles;
-  uint32_t expected;           // primary rays that survived the TLAS test in the slot's previous frame (grid sizing only)
-  float position[3], right[3], up[3], forward[3];
-  float4* ray_o_out;           // bounce-0 queue entries of the surviving rays, written next to their hit records
-  float4* ray_d_out;
-  uint32_t* tails_rw;          // counters + cnt_tail(0, 0)
-};
-
-// One primary sample (src/shader.rgen:62-79): lane = pixel of the 8x8 tile (tx, ty) of this shard's compact rows, i = sample
-// index.  Returns true when the ray enters a box of the TLAS root's two levels (it has to be traced); otherwise the sample
-// is a miss and its sky colour is already written.  Shared by k_raygen and the fused kernel: ONE arithmetic.
-__device__ __forceinline__ bool gen_primary(const SceneDev& sc, const GenArgs& g, float4* sample_color, uint32_t tx, uint32_t ty,
-                                            uint32_t i, uint32_t lane, F3& d, uint32_t& sid) {
-  const uint32_t x = tx * 8u + (lane & 7u);
-  const uint32_t ly = ty * 8u + (lane >> 3);
-  d = mk3(0.f, 0.f, 1.f); sid = 0;
-  if (!(i < g.spp && x < (uint32_t)g.width && ly < (uint32_t)g.rows)) return false;
-  uint32_t y = ly;   // local row -> frame row of this shard's interleaved bands
-  if (g.n_shards != 1) {
-    const uint32_t band = g.band_rows == 8 ? ty : ly / (uint32_t)g.band_rows;
-    const uint32_t within = g.band_rows == 8 ? (lane >> 3) : ly % (uint32_t)g.band_rows;
-    y = (band * (uint32_t)g.n_shards + (uint32_t)g.shard) * (uint32_t)g.band_rows + within;
-  }
-  const float fx = (float)x, fy = (float)y;
-  const float seed0 = (float)(g.spp + i), seed1 = seed0 + 0.5f;
-  float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)g.width;
-  float uy = (fy + jitter_hash(fx, fy, seed1)) / (float)g.height;
-  ux = __builtin_fmaf(ux, 2.0f, -1.0f);
-  uy = -__builtin_fmaf(uy, 2.0f, -1.0f);
-  const F3 right = mk3(g.right[0], g.right[1], g.right[2]), up = mk3(g.up[0], g.up[1], g.up[2]), fwd = mk3(g.forward[0], g.forward[1], g.forward[2]);
-  d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
-  sid = i * (uint32_t)(g.rows * g.width) + ly * (uint32_t)g.width + x;
-  const F3 o = mk3(g.position[0], g.position[1], g.position[2]);
-  F3 qs, qb; uint3 rot;
-  quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
-  // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
-  const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
-  const uint4 Q0 = rp[0], Q1 = rp[1];
-  float tn;
-  const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
-  const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) && Q1.w != Q1.z;
-  const int c0 = (int)Q1.z, c1 = (int)Q1.w;
-  bool survive = (h0 && c0 < 0) || (h1 && c1 < 0);
-#pragma unroll
-  for (int k = 0; k < 2; k++) {
-    const int ch = k ? c1 : c0;
-    if ((k ? h1 : h0) && ch >= 0 && !survive) {
-      const uint4* np = reinterpret_cast<const uint4*>(sc.blas_nodes + ch);
-      const uint4 N0 = np[0], N1 = np[1];
-      survive = slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn);
-    }
-  }
-  if (!survive) {
-    const F3 c = sample_sky(sc, mk3(d.x, d.y, -d.z));
-    sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
-  }
-  return survive;
-}
-
-__host__ __device__ __forceinline__ GenArgs gen_args_of(const FrameDev& f, const UniformsDev& u) {
-  GenArgs g{};
-  g.width = f.width; g.height = f.height; g.rows = f.rows; g.band_rows = f.band_rows; g.n_shards = f.n_shards; g.shard = f.shard;
-  g.spp = u.samples_per_pixel;
-  for (int k = 0; k < 3; k++) { g.position[k] = u.position[k]; g.right[k] = u.right[k]; g.up[k] = u.up[k]; g.forward[k] = u.forward[k]; }
-  return g;
-}
-
 __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u) {
   // grid (tiles_x, tiles_y, sample groups), block (64 lanes = one 8x8 tile, up to 4 samples): no index division
+  const uint32_t spp = u.samples_per_pixel;
   const uint32_t lane = threadIdx.x;
   const uint32_t i = blockIdx.z * blockDim.y + threadIdx.y;
-  const GenArgs g = gen_args_of(f, u);
-  F3 d; uint32_t sid;
-  const bool survive = gen_primary(sc, g, f.sample_color, blockIdx.x, blockIdx.y, i, lane, d, sid);
+  const uint32_t x = blockIdx.x * 8u + (lane & 7u);
+  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  const bool live = i < spp && x < (uint32_t)f.width && ly < (uint32_t)f.rows;
+  bool survive = false;
+  F3 d = mk3(0.f, 0.f, 1.f);
+  uint32_t sid = 0;
+  if (live) {
+    uint32_t y = ly;   // local row -> frame row of this shard's interleaved bands
+    if (f.n_shards != 1) {
+      const uint32_t band = f.band_rows == 8 ? blockIdx.y : ly / (uint32_t)f.band_rows;
+      const uint32_t within = f.band_rows == 8 ? (lane >> 3) : ly % (uint32_t)f.band_rows;
+      y = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + within;
+    }
+    const float fx = (float)x, fy = (float)y;
+    const float seed0 = (float)(spp + i), seed1 = seed0 + 0.5f;
+    float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)f.width;
+    float uy = (fy + jitter_hash(fx, fy, seed1)) / (float)f.height;
+    ux = __builtin_fmaf(ux, 2.0f, -1.0f);
+    uy = -__builtin_fmaf(uy, 2.0f, -1.0f);
+    F3 right = mk3(u.right[0], u.right[1], u.right[2]), up = mk3(u.up[0], u.up[1], u.up[2]), fwd = mk3(u.forward[0], u.forward[1], u.forward[2]);
+    d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
+    sid = i * (uint32_t)(f.rows * f.width) + ly * (uint32_t)f.width + x;
+    const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
+    F3 qs, qb; uint3 rot;
+    quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
+    // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
+    const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
+    const uint4 Q0 = rp[0], Q1 = rp[1];
+    float tn;
+    const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
+    const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) && Q1.w != Q1.z;
+    const int c0 = (int)Q1.z, c1 = (int)Q1.w;
+    survive = (h0 && c0 < 0) || (h1 && c1 < 0);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      const int ch = k ? c1 : c0;
+      if ((k ? h1 : h0) && ch >= 0 && !survive) {
+        const uint4* np = reinterpret_cast<const uint4*>(sc.blas_nodes + ch);
+        const uint4 N0 = np[0], N1 = np[1];
+        survive = slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn);
+      }
+    }
+    if (!survive) {
+      const F3 c = sample_sky(sc, mk3(d.x, d.y, -d.z));
+      f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
+    }
+  }
   // workgroups are handed to the XCDs round-robin in linear order
   const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & (N_SHARDS - 1);
   const uint32_t slot = wave_alloc(survive, f.counters + cnt_tail(0, (int)shard));
@@ -407,7 +381,6 @@ struct TraceArgs {
   float tmin;
   uint32_t rays_per_lane;      // device-side grid sizing (variant 0): blocks beyond total/(256*rays_per_lane) exit
   uint32_t min_blocks;
-  GenArgs gen;                 // fused ray generation (trace_body<..., GEN>): bounce 0 without k_raygen and without a primary-ray queue
 };
 
 constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
@@ -455,9 +428,8 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 #define PH_END(k)
 #endif
 
-template <int MODE, bool ANY, bool COUNT, bool WIDE, bool GEN = false>
+template <int MODE, bool ANY, bool COUNT, bool WIDE>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
-  static_assert(!GEN || (MODE == MODE_CLOSEST && !WIDE), "fused ray generation: closest-hit pipeline kernel of variant 0 only");
   __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
@@ -475,11 +447,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   // few rays per lane runs faster on fewer, less contended waves that refill (every ray costs ~25-40 dependent
   // trips, and a trip is quickest with 1-2 waves per SIMD) — surplus blocks leave at once.
   {
-    uint32_t total = GEN ? a.gen.expected : 0u;
-    if (!GEN) {
+    uint32_t total = 0;
 #pragma unroll
-      for (int t = 0; t < N_SHARDS; t++) total += ld_cursor(a.tails + t * CNT_STRIDE);
-    }
+    for (int t = 0; t < N_SHARDS; t++) total += ld_cursor(a.tails + t * CNT_STRIDE);
     uint32_t want = (total + 256u * a.rays_per_lane - 1u) / (256u * a.rays_per_lane);
     want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
     if (want < a.min_blocks) want = a.min_blocks;
@@ -529,73 +499,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
     prefetch();
   };
-  if (!GEN) { prefetch(); promote(); }
-
-  // ---- fused ray generation (GEN): the work unit is one 8x8 pixel tile with all its samples; tile t belongs to shard t % 8
-  // (its hit records go there, so a shard's capacity bounds what it can receive), claimed from the shard's cursor one claim
-  // ahead (the returning atomic is in flight while the wave traverses); a wave whose shard is dry steals from the next.
-  // The samples of a tile are generated one 64-lane chunk at a time into the wave's ring in LDS (s_rays[wave][0]: d.xyz, sid),
-  // only when the ring is empty; misses are shaded and stored on the spot (gen_primary).
-  uint32_t g_shard = blockIdx.x & (N_SHARDS - 1), g_tried = 0, g_pend = 0;
-  uint32_t g_tile = 0, g_tx = 0, g_ty = 0, g_i = 0, g_tile_shard = 0;
-  bool g_have_tile = false;
-  auto g_limit = [&](uint32_t sh) -> uint32_t { return a.gen.n_tiles > sh ? (a.gen.n_tiles - sh + (N_SHARDS - 1)) / N_SHARDS : 0u; };
-  auto g_issue = [&]() { if (lane == 0) g_pend = atomicAdd(a.work + g_shard * CNT_STRIDE, 1u); };
-  auto g_take = [&]() -> bool {   // next tile of this wave; false when every shard is dry
-    while (g_tried < (uint32_t)N_SHARDS) {
-      const uint32_t k = (uint32_t)__builtin_amdgcn_readfirstlane((int)g_pend);
-      if (k < g_limit(g_shard)) {
-        g_tile = k * N_SHARDS + g_shard; g_tile_shard = g_shard;
-        g_ty = g_tile / a.gen.tiles_x; g_tx = g_tile - g_ty * a.gen.tiles_x;
-        g_i = 0;
-        g_issue();
-        return true;
-      }
-      g_shard = (g_shard + 1u) & (N_SHARDS - 1); g_tried++;
-      if (g_tried < (uint32_t)N_SHARDS) g_issue();
-    }
-    return false;
-  };
-  if (GEN) { g_issue(); g_have_tile = g_take(); }
-  uint32_t ring_count = 0, ring_pos = 0, ring_shard = 0;
-  auto g_generate = [&]() -> bool {   // one chunk into the (empty) ring; false when there is nothing left to generate
-    if (g_have_tile && g_i == a.gen.spp) g_have_tile = g_take();
-    if (!g_have_tile) return false;
-    F3 gd; uint32_t gsid;
-    const bool survive = gen_primary(a.sc, a.gen, a.sample_color, g_tx, g_ty, g_i, lane, gd, gsid);
-    const uint64_t m = __ballot(survive);
-    if (survive) s_rays[wave][0][prefix_rank(m)] = make_float4(gd.x, gd.y, gd.z, __uint_as_float(gsid));
-    ring_count = (uint32_t)__builtin_popcountll(m); ring_pos = 0; ring_shard = g_tile_shard;
-    g_i++;
-    return true;
-  };
-  uint32_t my_shard = 0;   // GEN: the shard of the lane's current ray
-  // GEN: every ray starts at the camera with tmax 10000 (src/shader.rgen:79,87) — wave-uniform, not per-lane state
-  const F3 cam = mk3(a.gen.position[0], a.gen.position[1], a.gen.position[2]);
+  prefetch();
+  promote();
 
   uint32_t out_count = 0;
   auto flush = [&]() {
-    if (GEN) {
-      // the results of one burst may belong to different shards (stolen tiles): one wave-aggregated allocation per shard present
-      const bool v = lane < out_count;
-      const int2 k = v ? s_outq[wave][lane] : make_int2(0, 0);   // (shard, instance)
-      uint64_t todo = __ballot(v);
-      uint32_t idx = 0;
-      while (todo != 0) {
-        const int s0 = __builtin_amdgcn_readlane(k.x, (int)__builtin_ctzll(todo));
-        const bool mine = v && k.x == s0;
-        const uint32_t slot = wave_alloc(mine, a.gen.tails_rw + (uint32_t)s0 * CNT_STRIDE);
-        if (mine) idx = (uint32_t)s0 * a.shard_cap + slot;
-        todo &= ~__ballot(mine);
-      }
-      if (v) {
-        a.hit_a[idx] = s_out[wave][lane]; a.hit_inst[idx] = k.y;
-        a.gen.ray_d_out[idx] = s_rays[wave][1][lane];
-        a.gen.ray_o_out[idx] = make_float4(a.gen.position[0], a.gen.position[1], a.gen.position[2], 10000.0f);
-      }
-      out_count = 0;
-      return;
-    }
     if (lane < out_count) {
       const float4 r = s_out[wave][lane];
       const int2 k = s_outq[wave][lane];
@@ -647,38 +555,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     PH_BEGIN(5)
     const uint64_t need_mask = __ballot(need);
     const uint32_t n_need = (uint32_t)__builtin_popcountll(need_mask);
-    if (GEN) {
-      if (n_need >= REFILL_MIN || n_need == 64u) {
-        uint64_t nm = need_mask;
-        bool more = true;
-        for (;;) {
-          const uint32_t avail = ring_count - ring_pos;
-          const uint32_t nn = (uint32_t)__builtin_popcountll(nm);
-          if (avail != 0 && nn != 0) {
-            const uint32_t rank = prefix_rank(nm);
-            const bool take = need && rank < avail;
-            if (take) {
-              const float4 rd = s_rays[wave][0][ring_pos + rank];
-              sid = __float_as_uint(rd.w);
-              wd = mk3(rd.x, rd.y, rd.z);
-              co = cam; cd = wd;
-              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
-              best_t = 10000.0f; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
-              cur_inst = -1;
-              stk[0] = REF_DONE; sp = 1;
-              cur = a.sc.tlas_root;
-              my_shard = ring_shard;
-              need = false;
-            }
-            ring_pos += nn < avail ? nn : avail;
-            nm = __ballot(need);
-          }
-          if (ring_pos < ring_count || nm == 0) break;        // every needy lane is served
-          if (!g_generate()) { more = false; break; }
-        }
-        if (!more && __ballot(need) == ~0ull) { flush(); break; }   // nothing left to generate and every lane idle
-      }
-    } else
     if (n_need >= REFILL_MIN || n_need == 64u) {
       if (chunk_pos == chunk_count && pf_count > 0) promote();
       if (chunk_pos < chunk_count) {
@@ -848,7 +724,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
         if (COUNT) cnt_tris++;
         float tt, uu, vv;
-        if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), (ANY ? best_t : (GEN ? 10000.0f : tmax)), tt, uu, vv)) {
+        if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), (ANY ? best_t : tmax), tt, uu, vv)) {
           const int prim = (int)__float_as_uint(T2.y);
           const bool better = (best_inst < 0) || (tt < best_t) ||
                               (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
@@ -865,7 +741,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       // an interior TLAS node (a TLAS leaf sets up its own space, and the bottom sentinel ends the ray)
       cur_inst = -1;
       pop();
-      if (cur >= 0) quant_space(GEN ? cam : wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+      if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
     }
     PH_END(2)
     PH_BEGIN(3)
@@ -883,12 +759,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       }
       if ((__float_as_uint(qsc.w) & 0xFFu) == 0u) {
         pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
-        if (cur >= 0) quant_space(GEN ? cam : wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+        if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
       } else {
         float m[12];
         m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
         m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
-        co = xform_point(m, GEN ? cam : wo); cd = xform_vec(m, wd);
+        co = xform_point(m, wo); cd = xform_vec(m, wd);
         const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
         quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
         push(REF_MARK);
@@ -909,10 +785,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         if (MODE == MODE_SHADOW) {
           s_out[wave][slot].x = best_inst < 0 ? 1.0f : 0.0f;   // lit?
           s_outq[wave][slot] = make_int2((int)sid, (int)q);
-        } else if (GEN) {
-          s_out[wave][slot] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
-          s_outq[wave][slot] = make_int2((int)my_shard, best_inst);
-          s_rays[wave][1][slot] = make_float4(wd.x, wd.y, wd.z, __uint_as_float(sid));   // the ray of this hit record, for k_shade
         } else {
           s_out[wave][slot] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
           s_outq[wave][slot] = make_int2((int)q, best_inst);
@@ -945,8 +817,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
 
 template <int MODE, bool ANY, bool COUNT, bool WIDE>
 __global__ __launch_bounds__(256) void k_trace(TraceArgs a) { trace_body<MODE, ANY, COUNT, WIDE>(a); }
-// bounce 0 with fused ray generation; held to the register budget of 5 waves per SIMD (what its LDS admits anyway)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(5, 5))) void k_trace_gen(TraceArgs a) { trace_body<MODE_CLOSEST, false, false, false, true>(a); }
 
 // ---- variant 1: quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
 // 64-lane wavefront.
@@ -1534,20 +1404,6 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
-}
-
-// bounce 0 with the ray generation fused into the traversal kernel (variant 0): no k_raygen, no primary-ray queue
-void launch_trace_closest_gen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, uint32_t expected_rays, const LaunchCfg& cfg, hipStream_t s) {
-  TraceArgs a = make_args(sc, f.counters, 0, f.shard_cap, f.ovf_stack);
-  a.hit_a = f.hit_a; a.hit_inst = f.hit_inst; a.sample_color = f.sample_color;
-  a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
-  a.gen = gen_args_of(f, u);
-  a.gen.tiles_x = ((uint32_t)f.width + 7u) >> 3;
-  a.gen.n_tiles = a.gen.tiles_x * (((uint32_t)f.rows + 7u) >> 3);
-  a.gen.expected = expected_rays;
-  a.gen.ray_o_out = f.ray_o[0]; a.gen.ray_d_out = f.ray_d[0];
-  a.gen.tails_rw = f.counters + cnt_tail(0, 0);
-  hipLaunchKernelGGL(k_trace_gen, dim3(cfg.trace_blocks), dim3(256), 0, s, a);
 }
 
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s) {

@@ -150,7 +150,6 @@ struct rt_ctx {
   bool grid_user_set = false;      // "trace_blocks_per_cu" was set explicitly: keep it
   int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped at rt_create so that MAX_TAILS_IN_FLIGHT of them are always co-resident
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
-  int fused_raygen = 0;          // 1: bounce 0 generates its rays inside the traversal kernel (variant 0): no k_raygen, no primary-ray queue
   unsigned long long* h_stats = nullptr;   // pinned, device-visible StatSlot block written by k_resolve
   unsigned long long* d_stats = nullptr;
   bool last_empty = false;       // the last enqueued frame had no rows (nothing was launched)
@@ -541,9 +540,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // k_raygen block b appends to shard b % 8, so a shard never receives more than this many rays; paths
   // stay in their shard, so the bound holds for every later queue as well
   const size_t raygen_blocks = raygen_block_count(W, rows, u.samples_per_pixel);
-  // (the fused kernel hands tile t to shard t % 8 with all its samples)
-  const size_t shard_cap = std::max<size_t>(std::max<size_t>(256, ((raygen_blocks + N_SHARDS - 1) / N_SHARDS) * 256),
-                                            ((tiles + N_SHARDS - 1) / N_SHARDS) * (size_t)u.samples_per_pixel * 64);
+  const size_t shard_cap = std::max<size_t>(256, ((raygen_blocks + N_SHARDS - 1) / N_SHARDS) * 256);
   const size_t capacity = shard_cap * N_SHARDS;
   int r = ensure_frame(c, capacity); if (r) return r;
   FrameDev f = c->frame;
@@ -567,8 +564,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   c->cnt_parity ^= 1;
   {
     Span frame_span(c, CAT_FRAME, s);
-    const bool fused = c->fused_raygen && c->cfg.variant == 0 && !c->counting;
-    if (!fused) { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
+    { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
     // either strategy gives the same image); bounces before it run on the full persistent grid
     uint32_t tail_start = 0xFFFFFFFFu;
@@ -583,12 +579,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, c->tail_blocks, s);
         break;
       }
-      if (b == 0 && fused) {
-        // grid sizing hint: the rays that survived the TLAS test in this slot's previous frame (host-mapped, unsynchronised)
-        const unsigned long long prev = c->h_stats ? ((volatile unsigned long long*)c->h_stats)[STAT_QUEUE0] : 0ull;
-        const uint32_t expected = (uint32_t)std::min<unsigned long long>(prev ? prev : samples / 2, 0xFFFFFFFFull);
-        Span sp(c, CAT_TRACE, s); launch_trace_closest_gen(sc, f, u, expected, c->cfg, s);
-      } else { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
+      { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
       { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
@@ -727,7 +718,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->fused_raygen = parent->fused_raygen; c->out_rgba8 = parent->out_rgba8;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->out_rgba8 = parent->out_rgba8;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1038,7 +1029,6 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "output_rgba8 cannot change while a frame is pending");
     c->out_rgba8 = value != 0; return RT_OK;
   }
-  if (k == "fused_raygen") { c->fused_raygen = value != 0; return RT_OK; }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
   if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); for (rt_ctx* m : c->scene->members) m->blas_builder = value; return RT_OK; }

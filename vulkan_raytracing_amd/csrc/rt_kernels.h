@@ -62,8 +62,6 @@ struct LaunchCfg {
 size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
-// bounce 0 with ray generation fused into the traversal kernel (variant 0 only); expected_rays sizes the grid on the device
-void launch_trace_closest_gen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, uint32_t expected_rays, const LaunchCfg& cfg, hipStream_t s);
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
 void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
