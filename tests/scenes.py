@@ -120,6 +120,24 @@ def random_rays(n, seed, origin_radius=20.0, target_radius=4.0, tmin=0.001, tmax
     return rays
 
 
+def grazing_rays(n, seed):
+    """Rays for two_object_scene(teapot, cube) that run almost parallel to the xz plane: origins on a far ring, aimed at points
+    ON the top / bottom faces of the orbiting cube (centre (0,0,5), half size 1) and into the teapot's height range, with
+    the direction's y component between 1e-2 and 1e-7 of its length."""
+    rng = np.random.default_rng(seed)
+    rays = np.zeros((n, 8), np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    o = np.stack([20 * np.cos(ang), np.zeros(n), 20 * np.sin(ang)], 1)
+    face = rng.integers(0, 3, n)
+    tgt = np.stack([rng.uniform(-1, 1, n), rng.choice([-1.0, 1.0], n), 5 + rng.uniform(-1, 1, n)], 1)
+    tgt[face == 1] = np.stack([rng.uniform(-2.5, 2.5, n), rng.uniform(0.0, 1.6, n), rng.uniform(-1.5, 1.5, n)], 1)[face == 1]
+    o[:, 1] = tgt[:, 1] + rng.choice([-1.0, 1.0], n) * 10.0 ** rng.uniform(-7, -2, n) * 20.0
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    rays[:, 0:3] = o; rays[:, 3] = 0.001; rays[:, 4:7] = d; rays[:, 7] = 10000.0
+    return rays
+
+
 # ---- fixtures produced by interpreting the reference's own SPIR-V shaders (tests/golden/make_spirv_fixtures.py) ---------------
 class SpirvFixtureScene:
     def __init__(self, meta, bounces, pixels):

@@ -979,3 +979,72 @@ def test_row_n4_mtl_materials_and_instance_types(ctx):
     finally:
         c2.close()
 
+
+
+@pytest.mark.parametrize("name,mesh", [("cfg3", "standin"), ("cfg3", "limbs"), ("cfg4", "standin"), ("cfg5", "standin")])
+def test_baseline_workloads_whole_frame_at_full_size_against_the_oracle(ctx, name, mesh):
+    """The BASELINE configurations bench.py times, at their FULL size, every pixel against the oracle: cfg3 (1920x1080,
+    depth 4, real sea skybox) on both stand-in meshes, cfg4 (3840x2160, depth 6), cfg5 (16 instances, raised camera).
+    The oracle renders them on the GPU box's host cores (its own SAH BVH, all threads): 10-40 M rays each, a second or
+    two.  Bar: bit-identical on >= 99.9 % of the pixels, identical ray counts."""
+    import time
+    from vulkan_raytracing_amd import workloads
+    wl = workloads.make(name, RES, mesh=mesh)
+    wl.apply(ctx)
+    W, H = wl.width, wl.height
+    gpu, st = ctx.trace(W, H)
+    tgt = _OracleTarget()
+    wl.apply(tgt)
+    t0 = time.time()
+    ref, rc = tgt.orc.render(W, H)
+    print("oracle %s/%s: %.1f s for %d rays" % (name, mesh, time.time() - t0, int(rc.sum())))
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    assert st.rays_primary == W * H * 4 and st.rays_secondary > 0 and st.rays_shadow > 0
+
+
+def test_animated_cfg3_frames_at_full_size_against_the_oracle(ctx):
+    """bench.py's animated leg on its workload: cfg3 after 20 and 90 steps of the reference's animation
+    (src/main.cpp:2836-2851, fixed dt), each through rt_set_instances(update=1) = TLAS refit, whole 1920x1080 frames
+    against the oracle (which rebuilds its TLAS)."""
+    from vulkan_raytracing_amd import workloads
+    wl = workloads.make("cfg3", RES)
+    wl.apply(ctx)
+    tgt = _OracleTarget()
+    wl.apply(tgt)
+    W, H = wl.width, wl.height
+    ctx.trace(W, H)
+    t = np.float32(0.0)
+    for step in range(1, 91):
+        t = np.float32(t + np.float32(1.0 / 60.0) * np.float32(0.1))
+        inst = wl.animate(t)
+        if step in (20, 90):
+            ctx.set_instances(inst, update=True)
+            gpu, st = ctx.trace(W, H)
+            tgt.set_instances(inst)
+            ref, rc = tgt.orc.render(W, H)
+            check_image(gpu, ref)
+            assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+
+
+def test_grazing_rays_against_brute_force(ctx):
+    """Rays almost parallel to a coordinate plane that skim the axis-aligned faces of cube.obj (every box face of its tree
+    carries triangles) and the teapot: hit records of the HIP traversal (quantized boxes, slack in space) against the
+    oracle's BRUTE-FORCE mode, closest hit and any hit; and a TLAS whose instances are rotated so that the instance boxes
+    are grazed as well."""
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 1, 1, ctx=ctx)
+    rays = scenes.grazing_rays(60000, seed=11)
+    g, _ = ctx.intersect(rays)
+    b = sp.orc.intersect(rays, use_bvh=False)
+    assert (b["inst"] >= 0).mean() > 0.2
+    same = (g["prim"] == b["prim"]) & (g["inst"] == b["inst"]) & (g["t"].view(np.uint32) == b["t"].view(np.uint32))
+    assert same.all(), int((~same).sum())
+    sh = rays.copy(); sh[:, 7] = 21.0
+    ga, _ = ctx.intersect(sh, any_hit=True)
+    clo = sp.orc.intersect(sh, use_bvh=False)
+    assert np.array_equal(ga["inst"] >= 0, clo["inst"] >= 0)
+    sp2 = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 1, 1, ctx=ctx, time_param=0.25)
+    g2, _ = ctx.intersect(rays)
+    b2 = sp2.orc.intersect(rays, use_bvh=False)
+    same2 = (g2["prim"] == b2["prim"]) & (g2["inst"] == b2["inst"]) & (g2["t"].view(np.uint32) == b2["t"].view(np.uint32))
+    assert same2.all(), int((~same2).sum())
