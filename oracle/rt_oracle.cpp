@@ -259,6 +259,7 @@ static inline bool tri_test(V3 o, V3 d, V3 v0, V3 e1, V3 e2, float tmin, float t
 // contract is conservativeness, checked against brute force in tests/test_oracle.py.
 struct BuildTri { float lo[3], hi[3], c[3]; uint32_t id; };
 
+static void pad_boxes(Mesh& m);
 static void build_mesh_bvh(const Scene& s, Mesh& m) {
   uint32_t n = m.prim_count;
   std::vector<BuildTri> tris(n);
@@ -340,22 +341,28 @@ static void build_mesh_bvh(const Scene& s, Mesh& m) {
   }
   m.order.resize(n);
   for (uint32_t i = 0; i < n; i++) m.order[i] = tris[i].id;
+  pad_boxes(m);
 }
 
 // Conservative slab test; only ever widens the accepted set.  The slack has to be in SPACE, not only in t: for a ray that
 // runs almost parallel to a box face (the rows through the image centre: |d.y| ~ 1e-4) an error of one ulp in (lo - o)
 // becomes an error of 1e-3 in t, so a relative slack on t alone loses triangles that lie ON the face and are grazed by the
 // ray (found on an animated cfg3 frame: 1 primary hit of 8.3 M differed from the brute-force mode, which the HIP path
-// matched).  Every plane is therefore pushed outwards by 1e-5 of the magnitudes involved before the division.
-static inline bool box_test(const BNode& b, V3 o, V3 id, float tmin, float tmax) {
-  const float px = 1e-5f * (fabsf(b.lo[0]) + fabsf(b.hi[0]) + fabsf(o.x)) + 1e-30f;
-  const float py = 1e-5f * (fabsf(b.lo[1]) + fabsf(b.hi[1]) + fabsf(o.y)) + 1e-30f;
-  const float pz = 1e-5f * (fabsf(b.lo[2]) + fabsf(b.hi[2]) + fabsf(o.z)) + 1e-30f;
-  float t0x = ((b.lo[0] - px) - o.x) * id.x, t1x = ((b.hi[0] + px) - o.x) * id.x;
-  float t0y = ((b.lo[1] - py) - o.y) * id.y, t1y = ((b.hi[1] + py) - o.y) * id.y;
-  float t0z = ((b.lo[2] - pz) - o.z) * id.z, t1z = ((b.hi[2] + pz) - o.z) * id.z;
-  float tn = std::max(std::max(std::min(t0x, t1x), std::min(t0y, t1y)), std::max(std::min(t0z, t1z), tmin));
-  float tf = std::min(std::min(std::max(t0x, t1x), std::max(t0y, t1y)), std::min(std::max(t0z, t1z), tmax));
+// matched).  Every plane is therefore pushed outwards by 1e-5 of the magnitudes involved: the box part once, when the tree
+// is built (pad_boxes), the ray-origin part per ray as a slack of 1e-5 * |o| * |1/d| on each axis' entry and exit distance.
+static void pad_boxes(Mesh& m) {
+  for (BNode& b : m.nodes)
+    for (int k = 0; k < 3; k++) {
+      const float p = 1e-5f * (fabsf(b.lo[k]) + fabsf(b.hi[k])) + 1e-30f;
+      b.lo[k] -= p; b.hi[k] += p;
+    }
+}
+static inline bool box_test(const BNode& b, V3 o, V3 id, V3 slack, float tmin, float tmax) {
+  float t0x = (b.lo[0] - o.x) * id.x, t1x = (b.hi[0] - o.x) * id.x;
+  float t0y = (b.lo[1] - o.y) * id.y, t1y = (b.hi[1] - o.y) * id.y;
+  float t0z = (b.lo[2] - o.z) * id.z, t1z = (b.hi[2] - o.z) * id.z;
+  float tn = std::max(std::max(std::min(t0x, t1x) - slack.x, std::min(t0y, t1y) - slack.y), std::max(std::min(t0z, t1z) - slack.z, tmin));
+  float tf = std::min(std::min(std::max(t0x, t1x) + slack.x, std::max(t0y, t1y) + slack.y), std::min(std::max(t0z, t1z) + slack.z, tmax));
   return tn <= tf * 1.0001f + 1e-5f;
 }
 static inline float safe_inv(float d) {
@@ -392,11 +399,12 @@ static bool trace(const Scene& s, V3 o, V3 d, float tmin, float tmax, bool any_h
     }
     if (m.nodes.empty()) continue;
     V3 id = mk(safe_inv(od.x), safe_inv(od.y), safe_inv(od.z));
+    const V3 slack = mk(1e-5f * fabsf(oo.x) * fabsf(id.x), 1e-5f * fabsf(oo.y) * fabsf(id.y), 1e-5f * fabsf(oo.z) * fabsf(id.z));
     int32_t stack[128]; int sp = 0; stack[sp++] = 0;
     while (sp) {
       const BNode& nd = m.nodes[stack[--sp]];
       if (cnt) cnt->nodes++;
-      if (!box_test(nd, oo, id, tmin, found ? best.t : tmax)) continue;
+      if (!box_test(nd, oo, id, slack, tmin, found ? best.t : tmax)) continue;
       if (nd.count) {
         for (uint32_t k = 0; k < nd.count; k++) { consider(m.order[nd.first + k]); if (any_hit && found) return true; }
       } else { stack[sp++] = nd.right; stack[sp++] = nd.left; }
