@@ -1048,3 +1048,54 @@ def test_grazing_rays_against_brute_force(ctx):
     b2 = sp2.orc.intersect(rays, use_bvh=False)
     same2 = (g2["prim"] == b2["prim"]) & (g2["inst"] == b2["inst"]) & (g2["t"].view(np.uint32) == b2["t"].view(np.uint32))
     assert same2.all(), int((~same2).sum())
+
+
+def test_degenerate_frames_and_empty_shards(ctx):
+    """Edge cases of the dispatch (src/main.cpp:2620-2624 with unusual extents): a 1x1 frame, frames smaller than one 8x8
+    tile, more shards than bands (some ranks render NOTHING and must leave their buffers and counters alone), a camera that
+    looks away from every object (every sample ends in k_raygen), maxBounceCount 0."""
+    import torch
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 2, 3, sky=scenes.synthetic_skybox(64), ctx=ctx)
+    for W, H in ((1, 1), (3, 2), (7, 9), (64, 1)):
+        gpu, st = ctx.trace(W, H)
+        ref, rc = sp.orc.render(W, H)
+        check_image(gpu, ref)
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    # 5 shards over a frame of two 8-row bands: shards 2, 3, 4 are empty
+    W, H, n = 96, 16, 5
+    full, st = ctx.trace(W, H)
+    rows_max = tiling.max_shard_rows(H, tiling.BAND_ROWS, n)
+    shards, total = [], 0
+    for s in range(n):
+        buf = torch.full((max(rows_max, 1), W, 4), -7.0, dtype=torch.float32, device="cuda:0")
+        ctx.trace_shard(W, H, tiling.BAND_ROWS, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+        stt = ctx.stats()
+        rows = ctx.shard_rows(H, tiling.BAND_ROWS, s, n)
+        assert rows == (8 if s < 2 else 0)
+        if rows == 0:
+            assert (stt.rays_primary, stt.rays_secondary, stt.rays_shadow) == (0, 0, 0)
+            assert bool((buf == -7.0).all())           # an empty shard writes nothing
+        total += stt.rays_primary + stt.rays_secondary + stt.rays_shadow
+        shards.append(buf.cpu().numpy()[:rows_max])
+    assert np.array_equal(tiling.assemble(shards, H, W, tiling.BAND_ROWS), full)
+    assert total == st.rays_primary + st.rays_secondary + st.rays_shadow
+    # a frame right after the empty ones is still correct (counter blocks ping-pong untouched)
+    again, _ = ctx.trace(W, H)
+    assert np.array_equal(again, full)
+    # camera turned away from both objects: only sky
+    u = sp.uniforms.copy()
+    u[0]["forward"][:3] = (0.0, 0.0, 1.0)
+    sp.set_uniforms(u)
+    gpu, st = ctx.trace(160, 90)
+    ref, rc = sp.orc.render(160, 90)
+    check_image(gpu, ref)
+    assert st.rays_secondary == 0 and st.rays_shadow == 0 and int(rc[1]) == 0 and int(rc[2]) == 0
+    # maxBounceCount 0: primary rays and their shadow rays only
+    u = sp.uniforms.copy()
+    u[0]["forward"][:3] = (0.0, 0.0, -1.0)
+    u[0]["max_bounce_count"] = 0
+    sp.set_uniforms(u)
+    gpu, st = ctx.trace(160, 90)
+    ref, rc = sp.orc.render(160, 90)
+    check_image(gpu, ref)
+    assert st.rays_secondary == 0 and (st.rays_primary, st.rays_shadow) == (int(rc[0]), int(rc[2]))
