@@ -1099,3 +1099,34 @@ def test_degenerate_frames_and_empty_shards(ctx):
     ref, rc = sp.orc.render(160, 90)
     check_image(gpu, ref)
     assert st.rays_secondary == 0 and (st.rays_primary, st.rays_shadow) == (int(rc[0]), int(rc[2]))
+
+
+def test_more_instances_than_the_lds_record_cache(ctx):
+    """k_trace stages the records of the first 32 instances in LDS and reads the others from global memory: 48 cubes on a
+    ring + the mirror teapot (49 instances, a 6-level TLAS), whole frame and hit records against the oracle, then the
+    same TLAS refitted after every instance moved."""
+    from vulkan_raytracing_amd import workloads
+    paths = [os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj")]
+    g = host.SceneGeometry(paths)
+    u = host.default_uniforms(max_bounce_count=2, samples_per_pixel=2, center_object_type=1, orbiting_object_type=0,
+                              orbiting_object_primitive_offset=g.orbiting_primitive_offset, orbiting_object_vertex_offset=g.orbiting_vertex_offset)
+    workloads.raised_camera(u)
+    inst = workloads.ring_instances(48, 12.0)
+    sp = scenes.ScenePair(paths, inst, u, sky=scenes.synthetic_skybox(64), ctx=ctx)
+    W, H = 320, 180
+    gpu, st = ctx.trace(W, H)
+    ref, rc = sp.orc.render(W, H)
+    check_image(gpu, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2]))
+    assert st.rays_secondary > 0 and st.rays_shadow > 0
+    rays = scenes.random_rays(30000, seed=9, origin_radius=30.0, target_radius=13.0)
+    gh, _ = ctx.intersect(rays)
+    oh = sp.orc.intersect(rays, use_bvh=False)
+    assert len(np.unique(oh["inst"][oh["inst"] >= 0])) > 40      # the rays reach instances beyond the first 32
+    same = (gh["prim"] == oh["prim"]) & (gh["inst"] == oh["inst"]) & (gh["t"].view(np.uint32) == oh["t"].view(np.uint32))
+    assert same.all(), int((~same).sum())
+    sp.set_instances(workloads.ring_instances(48, 12.0, phase=0.37), update=True)
+    gpu2, st2 = ctx.trace(W, H)
+    ref2, rc2 = sp.orc.render(W, H)
+    check_image(gpu2, ref2)
+    assert (st2.rays_primary, st2.rays_secondary, st2.rays_shadow) == (int(rc2[0]), int(rc2[1]), int(rc2[2]))
