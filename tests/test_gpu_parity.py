@@ -1130,3 +1130,65 @@ def test_more_instances_than_the_lds_record_cache(ctx):
     ref2, rc2 = sp.orc.render(W, H)
     check_image(gpu2, ref2)
     assert (st2.rays_primary, st2.rays_secondary, st2.rays_shadow) == (int(rc2[0]), int(rc2[1]), int(rc2[2]))
+
+
+def test_primary_ray_coverage_mask_is_result_identical(ctx):
+    """k_cover marks the 8x8-pixel tiles the meshes' frontier boxes project onto and k_raygen shades the samples of the other
+    tiles as misses without any box test (rt_set_param "primary_cover", default on).  It may only remove rays that would have
+    missed: frames and ray counts with the mask on and off are identical — ordinary camera, a camera INSIDE an instance's box
+    (a frontier box crosses the camera plane: everything marked), a sheared / non-unit camera basis, objects partly off
+    screen, band shards of 8 and 16 rows (mask on) and 5 rows (mask off) — fewer rays reach the traversal kernel, and the
+    frame equals the oracle's."""
+    import torch
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 408, 232
+
+    def both():
+        out = {}
+        for on in (1, 0):
+            ctx.set_param("primary_cover", on)
+            img, st = ctx.trace(W, H)
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.closest_rays)
+        ctx.set_param("primary_cover", 1)
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1]
+        return out
+
+    base_u = sp.uniforms.copy()
+    try:
+        out = both()
+        assert out[1][2] < 0.8 * out[0][2], (out[1][2], out[0][2])      # the mask removes rays that the instance boxes let through
+        ref, rc = sp.orc.render(W, H)
+        check_image(out[1][0], ref)
+        assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        # shards: 8- and 16-row bands use the mask, 5-row bands cannot (tiles would straddle bands)
+        for band, n in ((8, 3), (16, 2), (5, 3)):
+            rows_max = tiling.max_shard_rows(H, band, n)
+            shards = []
+            for s in range(n):
+                buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+                ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                ctx.synchronize()
+                shards.append(buf.cpu().numpy())
+            assert np.array_equal(tiling.assemble(shards, H, W, band), out[1][0])
+        # camera inside the orbiting mesh's bounding box, looking at the teapot
+        u = base_u.copy()
+        u[0]["position"][:3] = (0.3, 0.2, 5.2)
+        sp.set_uniforms(u); both()
+        # sheared, non-unit basis (the shader takes the vectors as they come, src/shader.rgen:74-79)
+        u = base_u.copy()
+        u[0]["right"][:3] = (1.3, 0.2, 0.1); u[0]["up"][:3] = (0.15, 0.8, -0.1); u[0]["forward"][:3] = (0.1, -0.05, -1.4)
+        sp.set_uniforms(u); o2 = both()
+        ref, rc = sp.orc.render(W, H)
+        check_image(o2[1][0], ref)
+        # objects partly off screen, and behind the camera
+        u = base_u.copy()
+        u[0]["position"][:3] = (3.5, 0.5, 9.0)
+        sp.set_uniforms(u); both()
+        u = base_u.copy()
+        u[0]["forward"][:3] = (0.0, 0.0, 1.0)
+        sp.set_uniforms(u); o3 = both()
+        assert o3[1][2] == 0 and o3[0][2] == 0
+    finally:
+        ctx.set_param("primary_cover", 1)
+        sp.set_uniforms(base_u)

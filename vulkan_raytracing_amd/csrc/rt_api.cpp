@@ -46,6 +46,7 @@ struct Mesh {
   int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays (before the hot-node reordering)
   int32_t root = 0;                        // index of the mesh's root node in the linked quantized array
   uint32_t tri_base = 0;
+  uint32_t cover_first = 0, cover_count = 0;   // the mesh's frontier boxes in Scene::d_cover_boxes (primary-ray coverage mask)
 };
 
 struct TimedSpan { int cat; hipEvent_t a, b; };
@@ -81,6 +82,8 @@ struct Scene {
   float4* d_tris = nullptr;
   size_t n_blas_nodes = 0, n_blas4 = 0, n_tris = 0;
   uint32_t n_hot = 0;                  // leading nodes of d_blas_nodes the traversal kernels keep in LDS (<= HOT_NODES)
+  float* d_cover_boxes = nullptr;      // object-space frontier boxes of all meshes, 6 floats each (k_cover)
+  uint32_t max_cover_count = 0;
   uint32_t tlas_cap = 1024;            // TLAS nodes per slot (grows when a sole owner needs more)
   bool arrays_ready = false;           // device node arrays allocated for (n_blas*, tlas_cap, variant)
   int variant = 0;                     // traversal variant the arrays were linked for
@@ -150,6 +153,10 @@ struct rt_ctx {
   bool grid_user_set = false;      // "trace_blocks_per_cu" was set explicitly: keep it
   int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped at rt_create so that MAX_TAILS_IN_FLIGHT of them are always co-resident
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
+  int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
+  uint32_t* d_cover_mask = nullptr;   // TWO masks of cover_alloc_words: frame k uses one, its k_resolve clears the other
+  uint32_t cover_alloc_words = 0;
+  int cover_parity = 0;
   unsigned long long* h_stats = nullptr;   // pinned, device-visible StatSlot block written by k_resolve
   unsigned long long* d_stats = nullptr;
   bool last_empty = false;       // the last enqueued frame had no rows (nothing was launched)
@@ -324,6 +331,51 @@ int link_blas(rt_ctx* c) {
     for (auto& m : S->meshes) if (m.built && !m.qnodes.empty()) m.root = new_of[m.node_base]; else m.root = m.node_base;
     S->n_hot = (uint32_t)hot.size();
   }
+  // Frontier boxes for the primary-ray coverage mask (k_cover): walk every mesh breadth-first from its root until about
+  // COVER_TARGET_BOXES child boxes are open, and keep those boxes (dequantized: the stored planes already contain the float
+  // boxes with two quanta of margin) in object space.  A leaf met on the way contributes its box as it is.
+  {
+    std::vector<float> cover;
+    S->max_cover_count = 0;
+    size_t target = COVER_TARGET_BOXES;
+    if (const char* e = getenv("RT_COVER_BOXES")) { const long v = atol(e); if (v >= 2 && v <= (1 << 20)) target = (size_t)v; }   // experiments
+    for (auto& m : S->meshes) {
+      m.cover_first = (uint32_t)(cover.size() / 6); m.cover_count = 0;
+      if (!m.built || m.qnodes.empty()) continue;
+      auto emit = [&](const BvhNodeQ& q, int k) {
+        float lo[3], hi[3];
+        for (int ax = 0; ax < 3; ax++) {
+          const uint32_t w = q.w[3 * k + ax];
+          const uint32_t pl = w & 0xFFFFu, ph = w >> 16;
+          if (pl > ph) return;   // the absent child of a synthetic single-child root
+          lo[ax] = m.q_lo[ax] + (float)pl * m.q_scale[ax]; hi[ax] = m.q_lo[ax] + (float)ph * m.q_scale[ax];
+          const float pad = 1e-6f * (std::fabs(lo[ax]) + std::fabs(hi[ax]));
+          lo[ax] -= pad; hi[ax] += pad;
+        }
+        cover.insert(cover.end(), lo, lo + 3); cover.insert(cover.end(), hi, hi + 3);
+      };
+      std::vector<int32_t> frontier{m.root}, next;
+      size_t leaves = 0;
+      while (!frontier.empty() && leaves + 2 * frontier.size() < target) {
+        next.clear();
+        for (int32_t n : frontier) {
+          const BvhNodeQ& q = nodes[n];
+          const int32_t ch[2] = {q.child0, q.child1};
+          for (int k = 0; k < 2; k++) {
+            if (ch[k] >= 0) next.push_back(ch[k]);
+            else { emit(q, k); leaves++; }
+          }
+        }
+        frontier.swap(next);
+      }
+      for (int32_t n : frontier) { emit(nodes[n], 0); emit(nodes[n], 1); }
+      m.cover_count = (uint32_t)(cover.size() / 6) - m.cover_first;
+      S->max_cover_count = std::max(S->max_cover_count, m.cover_count);
+    }
+    if (S->d_cover_boxes) { HIP_TRY(c, hipFree(S->d_cover_boxes)); S->d_cover_boxes = nullptr; }
+    HIP_TRY(c, hipMalloc((void**)&S->d_cover_boxes, std::max<size_t>(6, cover.size()) * sizeof(float)));
+    if (!cover.empty()) HIP_TRY(c, hipMemcpy(S->d_cover_boxes, cover.data(), cover.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   S->variant = c->cfg.variant;
   std::vector<WideNodeQ> wide(S->variant == 2 ? nn : 0);   // only the variant that walks them pays for them
   if (S->variant == 2 && nn) widen_bvh2(nodes.data(), nn, 0, wide.data());
@@ -436,6 +488,7 @@ SceneDev scene_dev(const rt_ctx* c) {
   s.sky_w = S->sky_w; s.sky_h = S->sky_h;
   s.materials = S->d_materials; s.prim_material = S->d_prim_material; s.n_materials = S->n_materials;
   s.n_hot = S->n_hot;
+  s.cover_boxes = S->d_cover_boxes;
   for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
   return s;
 }
@@ -550,6 +603,41 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   const SceneDev sc = scene_dev(c);
+  // Primary-ray coverage mask: on when the bands are whole 8x8 tiles, the camera basis is invertible and the scene has boxes.
+  // The mask of this frame was cleared by the previous frame's k_resolve (or at allocation); this frame's clears the other.
+  CoverArgs ca{};
+  bool cover_on = c->primary_cover && rows > 0 && c->scene->max_cover_count > 0 && (n_shards == 1 || band_rows % 8 == 0) && c->cfg.variant != 1;
+  if (cover_on) {
+    const double R[9] = {u.right[0], u.up[0], u.forward[0], u.right[1], u.up[1], u.forward[1], u.right[2], u.up[2], u.forward[2]};   // columns right, up, forward
+    const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
+    const double scale = std::fabs(R[0]) + std::fabs(R[1]) + std::fabs(R[2]) + std::fabs(R[3]) + std::fabs(R[4]) + std::fabs(R[5]) + std::fabs(R[6]) + std::fabs(R[7]) + std::fabs(R[8]);
+    if (!(std::fabs(det) > 1e-6 * scale * scale * scale / 27.0) || !std::isfinite(det)) cover_on = false;
+    else {
+      const double id = 1.0 / det;
+      const double inv[9] = {(R[4] * R[8] - R[5] * R[7]) * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
+                             (R[5] * R[6] - R[3] * R[8]) * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
+                             (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+      for (int k = 0; k < 9; k++) ca.inv[k] = (float)inv[k];
+      for (int k = 0; k < 3; k++) ca.cam[k] = u.position[k];
+      ca.width = W; ca.height = H; ca.tiles_x = (W + 7) / 8; ca.tiles_y = (H + 7) / 8; ca.n_inst = (int)c->h_inst.size();
+    }
+  }
+  {
+    const uint32_t words = 1u + (uint32_t)((((size_t)((W + 7) / 8) * (size_t)((H + 7) / 8)) + 31) / 32);
+    if (cover_on && words > c->cover_alloc_words) {
+      if (c->d_cover_mask) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_cover_mask)); c->d_cover_mask = nullptr; c->cover_alloc_words = 0; }
+      HIP_TRY(c, hipMalloc((void**)&c->d_cover_mask, 2 * (size_t)words * sizeof(uint32_t)));
+      HIP_TRY(c, hipMemsetAsync(c->d_cover_mask, 0, 2 * (size_t)words * sizeof(uint32_t), c->stream));
+      HIP_TRY(c, hipStreamSynchronize(c->stream));
+      c->cover_alloc_words = words; c->cover_parity = 0;
+    }
+  }
+  if (c->d_cover_mask && rows > 0) {
+    // (a frame that does not use the mask still clears the next one, so that a later frame finds it clean)
+    f.cover = cover_on ? c->d_cover_mask + (size_t)c->cover_parity * c->cover_alloc_words : nullptr;
+    f.cover_next = c->d_cover_mask + (size_t)(c->cover_parity ^ 1) * c->cover_alloc_words;
+    f.cover_words = c->cover_alloc_words; f.cover_tiles_x = (W + 7) / 8;
+  }
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
   if (!c->timing || c->timed_frames >= 64) { c->ev_used = 0; c->spans.clear(); c->timed_frames = 0; }
@@ -562,9 +650,14 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload[c->parity], 0));
   if (rows == 0) return RT_OK;   // nothing is launched: both counter blocks stay zero
   c->cnt_parity ^= 1;
+  if (f.cover_next) c->cover_parity ^= 1;   // (f.cover / f.cover_next were taken above)
   {
     Span frame_span(c, CAT_FRAME, s);
-    { Span sp(c, CAT_RAYGEN, s); launch_raygen(sc, f, u, s); }
+    {
+      Span sp(c, CAT_RAYGEN, s);
+      if (f.cover) launch_cover(sc, ca, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
+      launch_raygen(sc, f, u, s);
+    }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
     // either strategy gives the same image); bounces before it run on the full persistent grid
     uint32_t tail_start = 0xFFFFFFFFu;
@@ -718,7 +811,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->out_rgba8 = parent->out_rgba8;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->primary_cover = parent->primary_cover; c->out_rgba8 = parent->out_rgba8;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -745,7 +838,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf,
+  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
@@ -760,7 +853,7 @@ void rt_destroy(rt_ctx* c) {
   S->slot_mask &= ~(1u << c->slot);
   size_traversal_grids(S);
   if (S->members.empty()) {   // the last context of a scene takes the shared arrays with it
-    void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky, S->d_materials, S->d_prim_material};
+    void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky, S->d_materials, S->d_prim_material, S->d_cover_boxes};
     for (void* p : sp) if (p) hipFree(p);
     delete S;
   }
@@ -873,7 +966,7 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     d.first_float = (uint32_t)m.range.first_float;
     d.first_index = (uint32_t)m.range.first_index;
     d.type = (size_t)i < c->inst_types.size() ? c->inst_types[i] : TYPE_BY_OBJECT_INDEX;
-    d.pad[0] = d.pad[1] = d.pad[2] = 0;
+    d.cover_first = m.cover_first; d.cover_count = m.range.prim_count ? m.cover_count : 0u; d.pad = 0;
     boxes[i] = instance_world_box(d.o2w, m.bounds);
   }
   if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
@@ -1029,6 +1122,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "output_rgba8 cannot change while a frame is pending");
     c->out_rgba8 = value != 0; return RT_OK;
   }
+  if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
   if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); for (rt_ctx* m : c->scene->members) m->blas_builder = value; return RT_OK; }

@@ -89,7 +89,8 @@ struct alignas(16) InstanceDev {
   float q_lo[3];        // dequantisation of the mesh's BvhNodeQ planes (object space)
   float q_scale[3];
   uint32_t type;        // per-instance object type (rt_set_instance_types) or TYPE_BY_OBJECT_INDEX: the reference's two-way switch
-  uint32_t pad[3];
+  uint32_t cover_first, cover_count;   // the mesh's frontier boxes in SceneDev::cover_boxes (primary-ray coverage mask, k_cover)
+  uint32_t pad;
 };
 static_assert(sizeof(InstanceDev) == 160, "InstanceDev must be 160 bytes");
 
@@ -125,6 +126,10 @@ constexpr uint32_t MATERIAL_NONE = 0xFFFFFFFFu;          // shadow-queue tag: th
 // under round-robin dispatch is their XCD: the rays a shard's producers write are read back through
 // the same XCD's L2, and no single atomic word sees more than 1/8 of the traffic (one returning
 // atomic word saturates near 88 operations/us on MI355X).  Placement is a speed hint, never assumed.
+// Primary-ray coverage mask (k_cover): every mesh contributes the boxes of its BLAS frontier at about COVER_TARGET_BOXES (1024 measured best: 256 .. 4096 give the same frame time, 16 384 costs more in k_cover than it culls)
+// nodes; a box whose screen rectangle spans more tiles than COVER_MAX_TILES marks the whole frame instead.
+constexpr int COVER_TARGET_BOXES = 1024;
+constexpr int COVER_MAX_TILES = 4096;
 constexpr int N_SHARDS = 8;
 constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: one 128-byte line each
 constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounceCount <= 69)

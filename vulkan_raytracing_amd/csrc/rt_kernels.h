@@ -26,6 +26,7 @@ struct SceneDev {
   const uint32_t* prim_material;  // material of every triangle of the index buffer (global primitive number = first_index / 3 + gl_PrimitiveID)
   int n_materials;
   uint32_t n_hot;              // nodes [0, n_hot) of blas_nodes are the hot set (<= HOT_NODES), staged through LDS by k_trace
+  const float* cover_boxes;    // object-space frontier boxes of every mesh (lo[3], hi[3]), InstanceDev::cover_first/count index them
 };
 
 struct FrameDev {
@@ -49,6 +50,22 @@ struct FrameDev {
   int width, height;           // full frame
   int rows;                    // rows rendered by this shard (compact)
   int band_rows, shard, n_shards;
+  // Primary-ray coverage mask of this frame (NULL: off).  Word 0 != 0: every tile may be covered; bit t of the words from 1 on:
+  // 8x8-pixel tile t = ty * cover_tiles_x + tx of the FULL frame may be touched by a mesh (k_cover); k_raygen shades the samples
+  // of an unmarked tile as misses without testing anything.  cover_next/cover_words: the slot's other mask, zeroed by k_resolve.
+  const uint32_t* cover;
+  uint32_t* cover_next;
+  uint32_t cover_words;
+  int cover_tiles_x;
+};
+
+// camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
+// the primary ray through P having ux = 2.5 a.x / a.z, uy = 2.5 a.y / a.z (src/shader.rgen:74-79)
+struct CoverArgs {
+  float cam[3];
+  float inv[9];
+  int width, height, tiles_x, tiles_y;
+  int n_inst;
 };
 
 struct LaunchCfg {
@@ -67,6 +84,8 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
+// marks the tiles of `mask` (FrameDev::cover layout) that the frontier boxes of the instances project onto
+void launch_cover(const SceneDev& sc, const CoverArgs& a, uint32_t max_boxes_per_instance, uint32_t* mask, hipStream_t s);
 // record-level traceRayEXT on raw rays: o = (o.xyz, tmin), d = (d.xyz, tmax); writes HitRec[n]
 // counters must hold the ray count in cnt_tail(0, 0) and zeros elsewhere; rays form shard 0 of capacity shard_cap
 void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, uint32_t shard_cap,
