@@ -32,8 +32,8 @@ if ROOT not in sys.path:
 # A 1/N frame shard is latency-bound (a lone 1/8 shard of cfg3 takes 0.45 ms, 0.16 ms of it the slowest rays of each traversal
 # launch), so a sharded run keeps more frames in flight and gives each of their streams its own hardware queue (HIP maps
 # streams onto 4 by default; read at HIP start-up).  Measured on one GPU (tools/pipeline_cost.py, profiles/r02_shard_ceiling.txt),
-# rank 0's shard of an 8-way split: 0.129 ms per frame with 4 slots / 4 queues, 0.112 with 8 / 8, 0.106-0.108 with 16 / 16
-# (= 5.9-6.2 x the whole frame's 0.64 ms); a whole frame gains nothing from more than 4, so a single-GPU run keeps the defaults.
+# rank 0's shard of an 8-way split: 0.131 ms per frame with 4 slots, 0.100-0.102 with 16 slots on 16 queues
+# (= 5.5 x the whole frame's 0.555 ms); a whole frame gains nothing from more than 4, so a single-GPU run keeps the defaults.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
