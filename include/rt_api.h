@@ -213,7 +213,10 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
  * the reference's storage image really has, src/main.cpp:1899) instead of RGBA32F — a quarter of the PCIe bytes;
  * "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device LBVH (default:
  * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357), 0 = host binned-SAH;
- * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids.  Results do not depend on any of them. */
+ * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids; "primary_cover" 1 (default) = before ray generation the
+ * frontier boxes of every instance's BLAS are projected onto 8x8-pixel screen tiles and the samples of tiles no mesh can
+ * project onto are shaded as misses without any box test, 0 = every primary ray is tested against the TLAS.
+ * Results do not depend on any of them. */
 int rt_set_param(rt_ctx* ctx, const char* name, int value);
 
 /* Record-level entry for traceRayEXT alone (rows a10/a14): n rays of 8 floats (o.xyz, tmin, d.xyz, tmax)
