@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <queue>
 #include <string>
 #include <vector>
 
@@ -354,21 +355,39 @@ int link_blas(rt_ctx* c) {
         }
         cover.insert(cover.end(), lo, lo + 3); cover.insert(cover.end(), hi, hi + 3);
       };
-      std::vector<int32_t> frontier{m.root}, next;
-      size_t leaves = 0;
-      while (!frontier.empty() && leaves + 2 * frontier.size() < target) {
-        next.clear();
-        for (int32_t n : frontier) {
-          const BvhNodeQ& q = nodes[n];
-          const int32_t ch[2] = {q.child0, q.child1};
-          for (int k = 0; k < 2; k++) {
-            if (ch[k] >= 0) next.push_back(ch[k]);
-            else { emit(q, k); leaves++; }
-          }
+      // open the LARGEST box first (object-space surface area) until `target` boxes are open: boxes of even size hug the
+      // silhouette better than the boxes of one tree level
+      struct Open { float area; int32_t parent; int k; int32_t ref; };
+      auto area_of = [&](const BvhNodeQ& q, int k) -> float {
+        float e[3];
+        for (int ax = 0; ax < 3; ax++) {
+          const uint32_t w = q.w[3 * k + ax];
+          const uint32_t pl = w & 0xFFFFu, ph = w >> 16;
+          if (pl > ph) return -1.0f;
+          e[ax] = (float)(ph - pl) * m.q_scale[ax];
         }
-        frontier.swap(next);
+        return e[0] * e[1] + e[1] * e[2] + e[2] * e[0];
+      };
+      auto cmp = [](const Open& x, const Open& y) { return x.area < y.area; };
+      std::priority_queue<Open, std::vector<Open>, decltype(cmp)> open(cmp);
+      std::vector<Open> closed;   // leaves: final as they are
+      auto push_children = [&](int32_t n) {
+        const BvhNodeQ& q = nodes[n];
+        const int32_t ch[2] = {q.child0, q.child1};
+        for (int k = 0; k < 2; k++) {
+          const float ar = area_of(q, k);
+          if (ar < 0.0f) continue;   // the absent child of a synthetic single-child root
+          const Open o{ar, n, k, ch[k]};
+          if (ch[k] >= 0) open.push(o); else closed.push_back(o);
+        }
+      };
+      push_children(m.root);
+      while (!open.empty() && open.size() + closed.size() + 1 <= target) {
+        const Open o = open.top(); open.pop();
+        push_children(o.ref);
       }
-      for (int32_t n : frontier) { emit(nodes[n], 0); emit(nodes[n], 1); }
+      for (const Open& o : closed) emit(nodes[o.parent], o.k);
+      while (!open.empty()) { emit(nodes[open.top().parent], open.top().k); open.pop(); }
       m.cover_count = (uint32_t)(cover.size() / 6) - m.cover_first;
       S->max_cover_count = std::max(S->max_cover_count, m.cover_count);
     }
