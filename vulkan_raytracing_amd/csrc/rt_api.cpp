@@ -688,14 +688,17 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     for (uint32_t b = 0; b <= u.max_bounce_count; b++) {
       if (b == tail_start) {
         // every later bounce in one launch (src/shader.rgen:84 loop), leaving as soon as a queue is empty
-        // the grid follows the work: one lane per ray of the first tail bounce in the slot's previous frame, 8..tail_blocks
-        // workgroups (a multiple of the shard count) — the workgroups of k_tail hold their CU resources while they wait at the
-        // grid barriers, so a 64-workgroup grid for the 260 secondary rays of a 1/8 shard mostly waits
+        // the grid follows the work: one lane per ray of the first tail bounce in the slot's previous frame, 1..tail_blocks
+        // workgroups (any count works: the bodies steal from the other shards) — the workgroups of k_tail hold their CU
+        // resources while they wait at the grid barriers, so a 64-workgroup grid for the 260 secondary rays of a 1/8 shard
+        // mostly waits (1/8 shard with 16 slots in flight: 0.100 ms with 64 workgroups, 0.091 with 8, 0.088 with 2)
         int tb = c->tail_blocks;
         const uint32_t expect = ((volatile uint32_t*)c->h_hint)[b];
         if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !getenv("RT_TAIL_FULL_GRID")) {
-          const long want = (((long)expect + 255) / 256 + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
-          tb = (int)std::min<long>(c->tail_blocks, std::max<long>(N_SHARDS, want));
+          long want = ((long)expect + 255) / 256, lo = 1;
+          if (const char* e = getenv("RT_TAIL_MIN_BLOCKS")) lo = std::max(1L, atol(e));   // experiments
+          if (lo >= N_SHARDS) want = (want + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
+          tb = (int)std::min<long>(c->tail_blocks, std::max<long>(lo, want));
         }
         Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, tb, s);
         break;
