@@ -32,8 +32,8 @@ if ROOT not in sys.path:
 # A 1/N frame shard is latency-bound (a lone 1/8 shard of cfg3 takes 0.45 ms, 0.16 ms of it the slowest rays of each traversal
 # launch), so a sharded run keeps more frames in flight and gives each of their streams its own hardware queue (HIP maps
 # streams onto 4 by default; read at HIP start-up).  Measured on one GPU (tools/pipeline_cost.py, profiles/r02_shard_ceiling.txt),
-# rank 0's shard of an 8-way split: 0.131 ms per frame with 4 slots, 0.100-0.102 with 16 slots on 16 queues
-# (= 5.5 x the whole frame's 0.555 ms); a whole frame gains nothing from more than 4, so a single-GPU run keeps the defaults.
+# rank 0's shard of an 8-way split: 0.128 ms per frame with 4 slots, 0.087-0.088 with 16 slots on 16 queues
+# (= 6.2 x the whole frame's 0.541 ms; 4-way: 0.180 / 0.158); a whole frame gains nothing from more than 4, so a single-GPU run keeps the defaults.
 if int(os.environ.get("WORLD_SIZE", "1")) > 1:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -271,7 +271,7 @@ def main():
     n = world
     collective = n > 1 or args.force_collective
     assert args.gpus == n, "--gpus must equal the number of launched ranks"
-    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else (8 if n <= 4 else 16))
+    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else 16)
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
