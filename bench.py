@@ -220,7 +220,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots per GPU, each with its own stream; the reference keeps swapchainImageCount = minImageCount + 1 frames in "
-                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 up to two GPUs, 8 on four, 16 on eight — the smaller a rank's "
+                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 up to two GPUs, 16 from three on — the smaller a rank's "
                          "shard the more latency-bound its kernels, and frames in flight fill the gaps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the animated leg, the single-frame latency and the second mesh (profiling runs)")
