@@ -625,7 +625,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // Primary-ray coverage mask: on when the bands are whole 8x8 tiles, the camera basis is invertible and the scene has boxes.
   // The mask of this frame was cleared by the previous frame's k_resolve (or at allocation); this frame's clears the other.
   CoverArgs ca{};
-  bool cover_on = c->primary_cover && rows > 0 && c->scene->max_cover_count > 0 && (n_shards == 1 || band_rows % 8 == 0) && c->cfg.variant != 1;
+  bool cover_on = c->primary_cover && rows > 0 && c->scene->max_cover_count > 0 && (n_shards == 1 || band_rows % 8 == 0) && c->cfg.variant != 1 &&
+                  c->h_inst.size() <= 65535;   // (k_cover's grid has one row of workgroups per instance)
   if (cover_on) {
     const double R[9] = {u.right[0], u.up[0], u.forward[0], u.right[1], u.up[1], u.forward[1], u.right[2], u.up[2], u.forward[2]};   // columns right, up, forward
     const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
