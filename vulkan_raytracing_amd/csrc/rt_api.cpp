@@ -155,6 +155,8 @@ struct rt_ctx {
   int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped at rt_create so that MAX_TAILS_IN_FLIGHT of them are always co-resident
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
   int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
+  int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
+  bool tail_full_grid = false;
   uint32_t* d_cover_mask = nullptr;   // TWO masks of cover_alloc_words: frame k uses one, its k_resolve clears the other
   uint32_t cover_alloc_words = 0;
   int cover_parity = 0;
@@ -695,9 +697,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         // mostly waits (1/8 shard with 16 slots in flight: 0.100 ms with 64 workgroups, 0.091 with 8, 0.088 with 2)
         int tb = c->tail_blocks;
         const uint32_t expect = ((volatile uint32_t*)c->h_hint)[b];
-        if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !getenv("RT_TAIL_FULL_GRID")) {
-          long want = ((long)expect + 255) / 256, lo = 1;
-          if (const char* e = getenv("RT_TAIL_MIN_BLOCKS")) lo = std::max(1L, atol(e));   // experiments
+        if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !c->tail_full_grid) {
+          long want = ((long)expect + 255) / 256;
+          const long lo = c->tail_min_blocks;
           if (lo >= N_SHARDS) want = (want + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
           tb = (int)std::min<long>(c->tail_blocks, std::max<long>(lo, want));
         }
@@ -839,11 +841,13 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->cfg.variant = 0;
   c->tail_blocks = tail_grid(c->n_cu, tail_blocks_per_cu());   // 0: device too small for k_tail's co-residency guarantee
   if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
+  if (const char* env = getenv("RT_TAIL_MIN_BLOCKS")) c->tail_min_blocks = std::max(1, atoi(env));
+  if (getenv("RT_TAIL_FULL_GRID")) c->tail_full_grid = true;
   if (const char* env = getenv("RT_TRACE_VARIANT")) { const int v = atoi(env); c->cfg.variant = (v >= 0 && v <= 2) ? v : 0; }
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->primary_cover = parent->primary_cover; c->out_rgba8 = parent->out_rgba8;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->out_rgba8 = parent->out_rgba8;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
