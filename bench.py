@@ -283,7 +283,10 @@ def main():
     rig = Rig(wl, P, dev, local_rank, rank, n, args, collective)
     ctx = rig.ctxs[0]
 
-    ctx.set_timing(True)   # HIP events around every kernel of slot 0's frames (every P-th frame), on their own stream
+    # HIP events around the closest-hit traversal launches of slot 0's frames (every P-th frame), on their own stream.  Only that
+    # kernel is bracketed inside the timed region: an event record between two kernels costs ~10 us of idle GPU (their
+    # kernels otherwise run back to back), so bracketing all seven would slow every P-th frame by 50 us.
+    ctx.set_timing(2)
     # set-up, not a step: one frame per slot so that every slot has its ray queues allocated before the warm-up/timed steps
     for _ in range(P):
         rig.step()
@@ -291,7 +294,17 @@ def main():
     mark("set-up frames done")
     dt = rig.timed(args.steps, args.warmup, animate=args.animate)
     mark("timed region done")
-    st = ctx.stats()        # counters of slot 0's last frame + MEAN event times over all its timed frames (every P-th step)
+    st = ctx.stats()        # counters of slot 0's last frame + MEAN closest-hit launch time over all its timed frames (every P-th step)
+    # the other kernels' live times: a short continuation of the same loop (same frames in flight) with events around every kernel
+    if not args.animate:
+        ctx.set_timing(1)
+        for _ in range(max(3 * P, 12)):
+            rig.step()
+        rig.sync()
+        st_all = ctx.stats()
+    else:
+        st_all = st
+    ctx.set_timing(2)
     last_frame = None
     if args.save_image and rank == 0 and rig.frames[(rig.counter - 1) % P] is not None:
         last_frame = rig.frames[(rig.counter - 1) % P][:H].clone()   # the last frame of THE timed region
@@ -324,7 +337,7 @@ def main():
         for c in rig.ctxs:
             c.set_instances(wl.instances)
         rig.sync()
-        ctx.set_timing(True)
+        ctx.set_timing(1)
 
     result = None
     if rank == 0:
@@ -368,7 +381,7 @@ def main():
         mean_tris = cst.tri_tests / max(1, cst.closest_rays)
         # rays that entered the k_trace<closest> launches: survivors of the TLAS-root test, plus the secondary rays unless
         # k_tail handled bounces >= 1 (its own launch, reported under frame_kernel_ms.tail)
-        closest_rays_rank0 = st.closest_rays - (st.rays_secondary if st.ms_tail > 0 else 0)
+        closest_rays_rank0 = st.closest_rays - (st.rays_secondary if st_all.ms_tail > 0 else 0)
         alg_bytes = closest_rays_rank0 * (RAY_BYTES + HIT_BYTES + mean_nodes * cst.bvh_node_bytes + mean_tris * cst.bvh_tri_bytes)
         launches = max(1, st.launches_trace_closest)
         live_s = st.ms_trace_closest * 1e-3
@@ -390,8 +403,10 @@ def main():
                                        "with the 5 per CU a lone slot gets)"},
                 "rays_per_frame_in_kernel": int(closest_rays_rank0), "mean_node_visits_per_ray": mean_nodes, "mean_tri_tests_per_ray": mean_tris,
                 "node_bytes": cst.bvh_node_bytes, "tri_bytes": cst.bvh_tri_bytes,
-                "frame_kernel_ms": {"raygen": st.ms_raygen, "trace_closest": st.ms_trace_closest, "shade": st.ms_shade,
-                                    "trace_shadow": st.ms_trace_shadow, "resolve": st.ms_resolve, "tail": st.ms_tail, "frame": st.ms_frame},
+                "frame_kernel_ms": {"raygen": st_all.ms_raygen, "trace_closest": st_all.ms_trace_closest, "shade": st_all.ms_shade,
+                                    "trace_shadow": st_all.ms_trace_shadow, "resolve": st_all.ms_resolve, "tail": st_all.ms_tail, "frame": st_all.ms_frame,
+                                    "timing": "a continuation of the timed loop (%d more steps, same frames in flight) with events around EVERY kernel of slot 0's frames; the "
+                                              "timed region itself brackets only the closest-hit launches (avg_launch_ms)" % max(3 * P, 12)},
                 "rocprof": None, "hbm_measured": None}
         # the two traversal kernels together over WALL time: with P frames in flight their launches overlap, so the per-launch
         # figure above (duration stretched by the other frames' kernels) understates what the chip delivers

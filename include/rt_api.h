@@ -203,7 +203,8 @@ int rt_shard_rows(int height, int band_rows, int shard, int n_shards);
 /* Wait for the last enqueued frame and read its counters / HIP-event timings. */
 int rt_synchronize(rt_ctx* ctx);
 int rt_get_stats(rt_ctx* ctx, rt_stats* stats);
-/* Enable per-kernel hipEvent timing (adds event records to the stream; default off). */
+/* Per-kernel hipEvent timing (default off): 1 = events around every kernel of a frame (each record between two kernels costs
+ * ~10 us of idle GPU), 2 = around the closest-hit traversal launches only (rt_stats.ms_trace_closest; the other times read 0). */
 int rt_set_timing(rt_ctx* ctx, int enabled);
 
 /* Tunables (no reference counterpart): "trace_variant" 0 = quantized BVH2 / one lane per ray (default), 1 = BVH4 /

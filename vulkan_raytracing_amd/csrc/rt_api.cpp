@@ -166,7 +166,7 @@ struct rt_ctx {
   uint32_t* h_hint = nullptr;    // pinned, device-visible array [CNT_MAX_BOUNCES]: bounce-queue sizes of the most recent finished
   uint32_t* d_hint = nullptr;    // frame (written by k_resolve; a speed hint only, never affects results)
   int blas_builder = 1;          // 1: device LBVH (bvh_gpu.hip, default), 0: host binned-SAH
-  bool timing = false;
+  int timing = 0;                // 0 off, 1 HIP events around every kernel, 2 around the closest-hit traversal launches only
   bool counting = false;
   std::vector<hipEvent_t> ev_pool;
   size_t ev_used = 0;
@@ -593,11 +593,14 @@ hipEvent_t take_event(rt_ctx* c) {
 
 struct Span {
   rt_ctx* c; int cat; hipStream_t s; hipEvent_t a = nullptr;
+  // An event record between two kernels costs ~10 us of idle GPU (measured: kernels of a frame run back to back without them),
+  // so the light mode brackets only the dominant kernel.
+  bool on() const { return c->timing == 1 || (c->timing == 2 && cat == CAT_TRACE); }
   Span(rt_ctx* c_, int cat_, hipStream_t s_) : c(c_), cat(cat_), s(s_) {
-    if (c->timing) { a = take_event(c); hipEventRecord(a, s); }
+    if (on()) { a = take_event(c); hipEventRecord(a, s); }
   }
   ~Span() {
-    if (c->timing) { hipEvent_t b = take_event(c); hipEventRecord(b, s); c->spans.push_back({cat, a, b}); }
+    if (on()) { hipEvent_t b = take_event(c); hipEventRecord(b, s); c->spans.push_back({cat, a, b}); }
   }
 };
 
@@ -1253,7 +1256,7 @@ int rt_debug_sizing(int n_cu, int resident_per_cu, int trace_blocks, uint32_t ov
   return RT_OK;
 }
 
-int rt_set_timing(rt_ctx* c, int enabled) { if (!c) return RT_ERR_INVALID_ARGUMENT; c->timing = enabled != 0; return RT_OK; }
+int rt_set_timing(rt_ctx* c, int enabled) { if (!c) return RT_ERR_INVALID_ARGUMENT; c->timing = enabled == 2 ? 2 : (enabled != 0); return RT_OK; }
 
 int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t out_capacity_bytes, void* hip_stream) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
