@@ -700,7 +700,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         // mostly waits (1/8 shard with 16 slots in flight: 0.100 ms with 64 workgroups, 0.091 with 8, 0.088 with 2)
         int tb = c->tail_blocks;
         const uint32_t expect = ((volatile uint32_t*)c->h_hint)[b];
-        if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !c->tail_full_grid) {
+        // (a lone slot keeps the full grid: nobody else needs the room and 64 workgroups finish 2 k rays in 43 us, 9 in 55)
+        if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !c->tail_full_grid && c->scene->members.size() >= 3) {
           long want = ((long)expect + 255) / 256;
           const long lo = c->tail_min_blocks;
           if (lo >= N_SHARDS) want = (want + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
