@@ -3,7 +3,7 @@
 teapot.obj (mirror) + armadillo (diffuse; a STAND-IN mesh unless resources/armadillo.obj is supplied) +
 skybox_texture_sea, 1920x1080, depth 4 (maxBounceCount 3) + shadow rays, spp 4.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts the N ranks itself, see launcher.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One process per GPU.  Per GPU ONE scene (geometry, BLAS, cube map) resident in HBM and --frames-in-flight frame slots on
@@ -29,12 +29,60 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="frame slots per GPU, each with its own stream; the reference keeps swapchainImageCount = minImageCount + 1 frames in "
+                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 up to two GPUs, 16 from three on — the smaller a rank's "
+                         "shard the more latency-bound its kernels, and frames in flight fill the gaps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the animated leg, the single-frame latency and the second mesh (profiling runs)")
+    ap.add_argument("--param", action="append", default=[], help="rt_set_param NAME=VALUE on every context (experiments), repeatable")
+    ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
+    ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray; 2 = 4-ary records, one lane per ray")
+    ap.add_argument("--blocks-per-cu", type=int, default=None)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
+                    help="cfg3 (default, the headline): 1920x1080 depth 4; cfg4: 3840x2160 depth 6; cfg5: 16 instances of the armadillo BLAS, 1920x1080 depth 4")
+    ap.add_argument("--mesh", default="standin", choices=["limbs", "standin"],
+                    help="which stand-in replaces the missing resources/armadillo.obj: standin = the geodesic blob (default: the mesh of round 1, and by "
+                         "node visits per ray the harder of the two), limbs = the non-star-shaped figure; ignored when the real file is supplied")
+    ap.add_argument("--animate", action="store_true", help="make the animated loop THE timed region (value then counts animated frames); without it the animated loop is a second field")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
+                         "reassembly where only one GPU exists (its throughput is meaningless)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with one rank: still create the RCCL process group and run the per-frame gather (to itself) — a smoke test of the N > 1 code path")
+    ap.add_argument("--host", default="ranks", choices=["ranks", "multi"],
+                    help="N > 1: 'ranks' = one process per GPU over torch.distributed/RCCL (started by this script when no launcher did); "
+                         "'multi' = ONE process drives all N GPUs through librt_multi.so (include/rt_multi.h: RCCL called from C++, no per-step Python "
+                         "on the data path besides two ctypes calls)")
+    ap.add_argument("--loopback", action="store_true", help="--host multi only: N LOGICAL devices on cuda:0, shards moved by device copies instead of RCCL (rehearsal on one GPU)")
+    return ap.parse_args(argv)
+
+
+ARGS = parse_args() if __name__ == "__main__" else None
+
+# `python3 bench.py --gpus N` from a plain shell (no torchrun): this process — which has made no HIP or torch.cuda call, it
+# has not even imported torch — starts the N ranks as fresh child processes and relays rank 0's JSON line.
+if ARGS is not None and ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ and ARGS.host == "ranks":
+    from vulkan_raytracing_amd.launcher import spawn_ranks
+    rank_cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    if os.environ.get("RT_BENCH_RANK_CMD"):   # tests: what to start as a rank (checks the plumbing without a GPU)
+        import shlex
+        rank_cmd = shlex.split(os.environ["RT_BENCH_RANK_CMD"])
+    sys.exit(spawn_ranks(ARGS.gpus, rank_cmd))
+
 # A 1/N frame shard is latency-bound (a lone 1/8 shard of cfg3 takes 0.45 ms, 0.16 ms of it the slowest rays of each traversal
 # launch), so a sharded run keeps more frames in flight and gives each of their streams its own hardware queue (HIP maps
 # streams onto 4 by default; read at HIP start-up).  Measured on one GPU (tools/pipeline_cost.py, profiles/r02_shard_ceiling.txt),
 # rank 0's shard of an 8-way split: 0.128 ms per frame with 4 slots, 0.087-0.088 with 16 slots on 16 queues
 # (= 6.2 x the whole frame's 0.541 ms; 4-way: 0.180 / 0.158); a whole frame gains nothing from more than 4, so a single-GPU run keeps the defaults.
-if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or (ARGS is not None and ARGS.gpus > 1):
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
@@ -213,34 +261,7 @@ class Rig:
             c.close()
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=6)
-    ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="frame slots per GPU, each with its own stream; the reference keeps swapchainImageCount = minImageCount + 1 frames in "
-                         "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 up to two GPUs, 16 from three on — the smaller a rank's "
-                         "shard the more latency-bound its kernels, and frames in flight fill the gaps")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the animated leg, the single-frame latency and the second mesh (profiling runs)")
-    ap.add_argument("--param", action="append", default=[], help="rt_set_param NAME=VALUE on every context (experiments), repeatable")
-    ap.add_argument("--save-image", default=None, help="write the last frame as PFM (rank 0)")
-    ap.add_argument("--variant", type=int, default=None, help="traversal kernel: 0 = quantized BVH2, one lane per ray (default); 1 = BVH4, four lanes per ray; 2 = 4-ary records, one lane per ray")
-    ap.add_argument("--blocks-per-cu", type=int, default=None)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg3", "cfg4", "cfg5"],
-                    help="cfg3 (default, the headline): 1920x1080 depth 4; cfg4: 3840x2160 depth 6; cfg5: 16 instances of the armadillo BLAS, 1920x1080 depth 4")
-    ap.add_argument("--mesh", default="standin", choices=["limbs", "standin"],
-                    help="which stand-in replaces the missing resources/armadillo.obj: standin = the geodesic blob (default: the mesh of round 1, and by "
-                         "node visits per ray the harder of the two), limbs = the non-star-shaped figure; ignored when the real file is supplied")
-    ap.add_argument("--animate", action="store_true", help="make the animated loop THE timed region (value then counts animated frames); without it the animated loop is a second field")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="N > 1 ranks share cuda:0 and gather through gloo/CPU tensors: exercises rank->band mapping, gather and "
-                         "reassembly where only one GPU exists (its throughput is meaningless)")
-    ap.add_argument("--force-collective", action="store_true",
-                    help="with one rank: still create the RCCL process group and run the per-frame gather (to itself) — a smoke test of the N > 1 code path")
-    args = ap.parse_args()
-
+def main(args):
     # stdout carries exactly one JSON line: library banners (RCCL prints its version to fd 1) go to stderr
     sys.stdout.flush()
     saved_stdout = os.dup(1)
@@ -270,7 +291,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     n = world
     collective = n > 1 or args.force_collective
-    assert args.gpus == n, "--gpus must equal the number of launched ranks"
+    if args.gpus != n:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (start it as `python3 bench.py --gpus N`, which launches the ranks itself, "
+                         "or under torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, n))
     P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else 16)
 
     res = os.path.join(ROOT, "resources")
@@ -511,4 +534,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(ARGS)

@@ -338,10 +338,22 @@ def test_bench_two_ranks_on_one_gpu_reassemble_the_same_frame(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--save-image", a],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline", "--rehearse-on-one-gpu", "--save-image", b], env=env, capture_output=True, text=True, timeout=900)
+    # the plain-shell form the driver uses for N = 1: bench.py starts the two ranks itself (vulkan_raytracing_amd/launcher.py)
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--rehearse-on-one-gpu", "--save-image", b], env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    import json
+    assert json.loads(lines[0])["n_gpus"] == 2
+    # ... and the launcher form of the contract (torch.distributed.run) gives the same frame
+    c = str(tmp_path / "two_torchrun.pfm")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-extras", "--rehearse-on-one-gpu", "--save-image", c], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(c, "rb").read() == open(b, "rb").read()
     fa, fb = open(a, "rb").read(), open(b, "rb").read()
     assert len(fa) == len(fb) and fa == fb
 

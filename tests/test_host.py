@@ -5,6 +5,8 @@ import json
 import os
 import re
 import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -366,3 +368,61 @@ def test_mtl_files_are_parsed(resources):
     assert g.ranges[0][2] == 2256
     txt = open(os.path.join(resources, "teapot.mtl")).read()
     assert "newmtl teapot" in txt and "Ni 1.450000" in txt
+
+
+_FAKE_RANK = r"""
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "ok":
+    print(json.dumps({"rank": rank, "n_gpus": world, "argv": sys.argv[2:]}), flush=True)   # only rank 0's line may reach the caller
+elif mode == "fail1":
+    if rank == 1:
+        sys.exit(7)
+    time.sleep(60)          # the survivors must be ended by the launcher, not waited for
+elif mode == "hang":
+    time.sleep(60)
+"""
+
+
+def test_launcher_starts_ranks_relays_rank0_and_propagates_failures(tmp_path):
+    """`python3 bench.py --gpus N` from a plain shell: vulkan_raytracing_amd/launcher.py starts N fresh rank processes with the
+    torch.distributed environment, hands through the command line, relays ONLY rank 0's stdout, returns the first non-zero
+    child status and ends the other ranks (exact PIDs).  The launcher itself never imports torch or a HIP library."""
+    import io
+    from vulkan_raytracing_amd import launcher
+    src = open(launcher.__file__).read()
+    assert "import torch" not in src and "ctypes" not in src and "hip" not in src.replace("HIP", "").replace("shipped", "")
+    fake = tmp_path / "rank.py"
+    fake.write_text(_FAKE_RANK)
+
+    class Sink(io.StringIO):
+        def fileno(self):
+            raise OSError("no fd")
+    out, err = Sink(), Sink()
+    rc = launcher.spawn_ranks(3, [sys.executable, str(fake), "ok", "--gpus", "3", "--steps", "5"], out=out, err=err)
+    assert rc == 0
+    lines = [ln for ln in out.getvalue().splitlines() if ln.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"rank": 0, "n_gpus": 3, "argv": ["--gpus", "3", "--steps", "5"]}
+    t0 = time.time()
+    assert launcher.spawn_ranks(3, [sys.executable, str(fake), "fail1"], out=Sink(), err=Sink()) == 7
+    assert time.time() - t0 < 30, "the launcher waited for ranks it should have ended"
+    assert launcher.spawn_ranks(2, [sys.executable, str(fake), "hang"], out=Sink(), err=Sink(), timeout_s=1.0) == 124
+    e0, e1 = launcher.rank_env(0, 2, 1234, base={}), launcher.rank_env(1, 2, 1234, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})
+    assert (e0["RANK"], e0["WORLD_SIZE"], e0["MASTER_PORT"], e0["HSA_ENABLE_IPC_MODE_LEGACY"]) == ("0", "2", "1234", "0")
+    assert e1["LOCAL_RANK"] == "1" and e1["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"     # an explicit setting is kept
+
+
+def test_bench_parent_launches_ranks_before_any_gpu_use(tmp_path):
+    """bench.py --gpus 2 without WORLD_SIZE must hand over to the launcher BEFORE importing torch (the parent may never touch
+    the GPU); checked here by running it with a stand-in interpreter environment in which the ranks only echo their environment:
+    RT_BENCH_RANK_CMD replaces the rank command line."""
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"],
+                       env=dict(os.environ, RT_BENCH_RANK_CMD=sys.executable + " -c \"import os,sys;print(os.environ['RANK']+'/'+os.environ['WORLD_SIZE']);sys.exit(3 if os.environ['RANK']=='1' else 0)\""),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3, (r.returncode, r.stderr[-1500:])
+    assert r.stdout.strip() == "0/2"
+    assert "| torch" not in r.stderr and "torch.cuda" not in r.stderr, "the launching parent imported torch"
