@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from tests import scenes
-from vulkan_raytracing_amd import RtContext, host, tiling
+from vulkan_raytracing_amd import RtContext, host, tiling, workloads
 from vulkan_raytracing_amd.api import RtError
 
 pytestmark = pytest.mark.gpu
@@ -1204,3 +1204,129 @@ def test_primary_ray_coverage_mask_is_result_identical(ctx):
     finally:
         ctx.set_param("primary_cover", 1)
         sp.set_uniforms(base_u)
+
+
+def test_entry_points_are_result_identical(ctx):
+    """k_entry gives every covered 8x8-pixel tile a short list of deep subtrees (its beam against the TLAS and the nearest
+    instance's BLAS) and the primary rays of the tile start their walk there instead of at the TLAS root (rt_set_param
+    "entry_points", default on).  The list must contain everything a ray of the tile can hit: frames, ray counts and the
+    number of rays that reach the traversal kernel are identical with it on and off or it removed a hit; the frame equals the
+    oracle's; node visits per ray drop.  Cameras: the start-up one, inside an instance's box, a sheared basis, objects partly
+    off screen / behind the camera; band shards; 17 instances (more TLAS words than a record holds); a one-instance scene."""
+    import torch
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 408, 232
+
+    def both(w=W, h=H):
+        out = {}
+        for on in (1, 0):
+            ctx.set_param("entry_points", on)
+            img, st = ctx.trace(w, h, counting=True)
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.closest_rays, st.node_visits)
+        ctx.set_param("entry_points", 1)
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1]
+        assert out[1][2] <= out[0][2]          # empty tiles only remove rays
+        return out
+
+    base_u = sp.uniforms.copy()
+    try:
+        out = both()
+        assert out[1][3] < 0.85 * out[0][3], (out[1][3], out[0][3])      # fewer node visits for the same result
+        ref, rc = sp.orc.render(W, H)
+        check_image(out[1][0], ref)
+        assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        for band, n in ((8, 3), (16, 2)):
+            rows_max = tiling.max_shard_rows(H, band, n)
+            shards = []
+            for s in range(n):
+                buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+                ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                ctx.synchronize()
+                shards.append(buf.cpu().numpy())
+            assert np.array_equal(tiling.assemble(shards, H, W, band), out[1][0])
+        u = base_u.copy()
+        u[0]["position"][:3] = (0.3, 0.2, 5.2)            # inside the orbiting mesh's box
+        sp.set_uniforms(u); both()
+        u = base_u.copy()
+        u[0]["right"][:3] = (1.3, 0.2, 0.1); u[0]["up"][:3] = (0.15, 0.8, -0.1); u[0]["forward"][:3] = (0.1, -0.05, -1.4)
+        sp.set_uniforms(u); o2 = both()
+        ref, rc = sp.orc.render(W, H)
+        check_image(o2[1][0], ref)
+        u = base_u.copy()
+        u[0]["position"][:3] = (3.5, 0.5, 9.0)            # partly off screen, very close
+        sp.set_uniforms(u); both()
+        u = base_u.copy()
+        u[0]["position"][:3] = (0.0, 0.0, 2000.0)         # far away: the whole scene inside a few tiles
+        sp.set_uniforms(u); both()
+        u = base_u.copy()
+        u[0]["forward"][:3] = (0.0, 0.0, 1.0)             # everything behind the camera
+        sp.set_uniforms(u); both()
+        # refractive centre mesh + deeper bounce budget: later bounces must be unaffected
+        u = base_u.copy()
+        u[0]["center_object_type"] = 2; u[0]["max_bounce_count"] = 5
+        sp.set_uniforms(u); both()
+    finally:
+        ctx.set_param("entry_points", 1)
+        sp.set_uniforms(base_u)
+    # 17 instances: the beam of a tile can meet more instances than a record has TLAS words
+    wl = workloads.make("cfg5", RES)
+    wl.apply(ctx, sky=scenes.synthetic_skybox(64))
+    o5 = both(480, 270)
+    assert o5[1][3] < o5[0][3]
+    # a single instance (synthetic TLAS root with an absent child) and a single-triangle-leaf mesh
+    wl1 = workloads.make("cfg1", RES)
+    wl1.apply(ctx)
+    both(256, 256)
+
+
+def test_shadow_entry_points_are_result_identical(ctx):
+    """Shadow rays all end (within 0.01) at the light, so k_entry also gives every tile of a cube around the light an entry list
+    and k_shade tells each shadow ray its tile (rt_set_param "shadow_entry", default on; "light_tiles" per cube side).  Any-hit
+    queries only ask WHETHER something is hit, so the lists must contain every possible occluder: frames and ray counts are
+    identical with the lists on and off, for lights outside, between and INSIDE the meshes' boxes, far away, on a cube-face
+    diagonal, next to a surface, for several light_tiles, for diffuse-on-diffuse scenes (every primary hit casts a shadow
+    ray), with 17 instances, and the frame equals the oracle's; shadow node visits per ray drop."""
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 0, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 408, 232
+
+    def both(w=W, h=H):
+        out = {}
+        for on in (1, 0):
+            ctx.set_param("shadow_entry", on)
+            img, st = ctx.trace(w, h, counting=True)
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.node_visits_shadow)
+        ctx.set_param("shadow_entry", 1)
+        assert out[1][1] == out[0][1]
+        assert np.array_equal(out[1][0], out[0][0]), "shadow entry lists changed %d pixels" % int((out[1][0] != out[0][0]).any(axis=2).sum())
+        return out
+
+    base_u = sp.uniforms.copy()
+    try:
+        out = both()
+        assert out[1][1][2] > 5000
+        assert out[1][2] < 0.8 * out[0][2], (out[1][2], out[0][2])
+        ref, rc = sp.orc.render(W, H)
+        check_image(out[1][0], ref)
+        assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        for light in ((0.0, 0.0, 12.0), (0.3, 0.2, 5.2), (0.0, 3.0, 2.5), (1000.0, 800.0, 600.0), (4.0, 4.0, 4.0), (-6.0, 0.01, 0.0), (0.0, 0.0, 0.0), (2.9, 0.0, 5.0)):
+            u = base_u.copy()
+            u[0]["light_position"][:3] = light
+            sp.set_uniforms(u); both()
+        sp.set_uniforms(base_u)
+        for lt in (8, 37, 512):
+            ctx.set_param("light_tiles", lt)
+            o = both()
+            assert np.array_equal(o[1][0], out[1][0])
+        ctx.set_param("light_tiles", 128)
+    finally:
+        ctx.set_param("shadow_entry", 1); ctx.set_param("light_tiles", 128)
+        sp.set_uniforms(base_u)
+    wl = workloads.make("cfg5", RES)
+    wl.apply(ctx, sky=scenes.synthetic_skybox(64))
+    o5 = both(480, 270)
+    assert o5[1][2] < o5[0][2]
+    wl1 = workloads.make("cfg1", RES)
+    wl1.apply(ctx)
+    both(256, 256)

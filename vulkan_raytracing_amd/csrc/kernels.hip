@@ -308,12 +308,15 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
 // behind the camera plane, or with a rectangle of more than COVER_MAX_TILES tiles, marks the whole frame.  k_raygen then shades
 // the samples of unmarked tiles as misses (src/shader.rmiss:11) without touching the TLAS: on cfg3 the rays handed to the
 // traversal kernel drop from 37 % of the samples (inside the instances' boxes) to about what really grazes the meshes.
-__global__ __launch_bounds__(256) void k_cover(SceneDev sc, CoverArgs a, uint32_t* mask) {
+__global__ __launch_bounds__(256) void k_cover(SceneDev sc, CoverViews views, uint32_t* mask_block) {
+  // blockIdx.z = view: 0 the camera, 1..6 the faces of the cube around the light (entry lists of the shadow rays)
+  const CoverArgs& a = views.v[blockIdx.z];
+  uint32_t* const mask = mask_block + a.mask_offset;
   const InstanceDev* I = sc.inst + blockIdx.y;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= I->cover_count || (I->mask & 0xFFu) == 0u) return;
   const float* bx = sc.cover_boxes + 6u * (size_t)(I->cover_first + b);
-  float x0 = 3e38f, x1 = -3e38f, y0 = 3e38f, y1 = -3e38f;
+  float x0 = 3e38f, x1 = -3e38f, y0 = 3e38f, y1 = -3e38f, az_min = 3e38f;
   bool all = false;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
@@ -324,14 +327,26 @@ __global__ __launch_bounds__(256) void k_cover(SceneDev sc, CoverArgs a, uint32_
     const float ay = a.inv[3] * v.x + a.inv[4] * v.y + a.inv[5] * v.z;
     const float az = a.inv[6] * v.x + a.inv[7] * v.y + a.inv[8] * v.z;
     if (!(az > 1e-20f)) { all = true; continue; }
-    const float ux = 2.5f * ax / az, uy = 2.5f * ay / az;
+    az_min = fminf(az_min, az);
+    const float ux = a.kf * ax / az, uy = a.kf * ay / az;
     const float px = (ux + 1.0f) * 0.5f * (float)a.width, py = (1.0f - uy) * 0.5f * (float)a.height;
     if (!(__builtin_fabsf(px) < 1e9f) || !(__builtin_fabsf(py) < 1e9f)) { all = true; continue; }
     x0 = fminf(x0, px); x1 = fmaxf(x1, px); y0 = fminf(y0, py); y1 = fmaxf(y1, py);
   }
   if (!all) {
     // one pixel of margin on every side, and a relative one for the rounding of the projection
-    const float mx = 1.0f + 1e-4f * (__builtin_fabsf(x0) + __builtin_fabsf(x1)), my = 1.0f + 1e-4f * (__builtin_fabsf(y0) + __builtin_fabsf(y1));
+    float mx = 1.0f + 1e-4f * (__builtin_fabsf(x0) + __builtin_fabsf(x1)), my = 1.0f + 1e-4f * (__builtin_fabsf(y0) + __builtin_fabsf(y1));
+    if (a.apex_radius > 0.0f) {
+      // rays that pass within apex_radius of the view point instead of through it (shadow rays at the light): a point of the box
+      // at depth az is then seen up to apex_radius (1 + |u|) / (az - apex_radius) away in u, u = kf ax / az (orthonormal light bases)
+      if (!(az_min > 4.0f * a.apex_radius)) all = true;
+      else {
+        const float g = a.apex_radius / (az_min - a.apex_radius) * 1.01f;
+        const float uxm = fmaxf(__builtin_fabsf(2.0f * x0 / (float)a.width - 1.0f), __builtin_fabsf(2.0f * x1 / (float)a.width - 1.0f));
+        const float uym = fmaxf(__builtin_fabsf(2.0f * y0 / (float)a.height - 1.0f), __builtin_fabsf(2.0f * y1 / (float)a.height - 1.0f));
+        mx += g * (a.kf + uxm) * 0.5f * (float)a.width; my += g * (a.kf + uym) * 0.5f * (float)a.height;
+      }
+    }
     const int ix0 = (int)floorf(x0 - mx), ix1 = (int)floorf(x1 + mx), iy0 = (int)floorf(y0 - my), iy1 = (int)floorf(y1 + my);
     if (ix1 < 0 || iy1 < 0 || ix0 >= a.width || iy0 >= a.height) return;   // the box is off screen
     const int tx0 = max(ix0, 0) >> 3, tx1 = min(ix1, a.width - 1) >> 3, ty0 = max(iy0, 0) >> 3, ty1 = min(iy1, a.height - 1) >> 3;
@@ -350,6 +365,262 @@ __global__ __launch_bounds__(256) void k_cover(SceneDev sc, CoverArgs a, uint32_
     }
   }
   if (all) atomicOr(mask, 1u);
+}
+
+constexpr int REF_DONE = (int)0x80000000;   // bottom-of-stack sentinel: the ray is finished
+constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both negative: not interior)
+
+// ------------------------------------------------------------------------------------------------
+// k_entry: entry-point search for the primary rays of one 8x8-pixel tile (all rays of a tile leave one point through one small
+// rectangle of directions, so what they can hit is decided ONCE per tile instead of once per ray).  One lane per tile walks the
+// TLAS, then the BLAS of the nearest instance, with the tile's BEAM — the cone {c > 0, ux0 c <= k a <= ux1 c, uy0 c <= k b <= uy1 c}
+// in camera coordinates (a, b, c) of src/shader.rgen:74-79 — instead of a ray: a child box that lies entirely on the outer side
+// of one of the beam's five planes cannot be entered by any ray of the tile and is dropped; a node with one surviving child is
+// replaced by that child; a node with two is split while the tile's list has room.  What is left is a handful of subtrees deep
+// in the tree (ENTRY_WORDS + 1 words) that together contain everything a ray of the tile can hit: the closest-hit kernel starts
+// the tile's rays there (trace_body<..., ENTRY>) instead of at the TLAS root.  The rule is conservative in the same sense as the
+// box tests of the traversal itself (quantized boxes contain the float boxes; every comparison carries a slack that covers the
+// binary32 evaluation), and the closest hit is the minimum over all candidates with a fixed tie rule, so frames are identical
+// with and without it (tested) — it only removes the ~11 upper levels of the walk from every primary ray.
+//
+// Record of a tile (EntryRec, 32 bytes): w[0] = number of stack words | instance << 8 (ENTRY_NO_INST: the rays start in world
+// space), w[1] = first node to visit, w[2..] = the words to push under it, bottom first: [TLAS words of the other instances /
+// unopened TLAS nodes, far to near] [REF_MARK] [BLAS nodes of the instance, far to near].  w[0] = ENTRY_EMPTY: the beam touches
+// nothing — k_raygen shades the tile's samples as misses.
+struct Plane5 {
+  float nx[5], ny[5], nz[5], d[5], slack[5];   // L_j(X) = nx X.x + ny X.y + nz X.z + d on QUANTIZED coordinates X
+  F3 qs, qb; uint3 rot;                        // the tile's CENTRE ray in the same space (slab_q form): orders the entries
+};
+
+// planes of the beam in world space: v = P - apex, (a, b, c) = inv * v
+__device__ __forceinline__ void beam_world(const EntryArgs& e, float ux0, float ux1, float uy0, float uy1, float wn[5][3], float wd[5], float wmag[5]) {
+  const float* ia = e.inv; const float* ib = e.inv + 3; const float* ic = e.inv + 6;
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    wn[0][k] = e.kf * ia[k] - ux0 * ic[k];
+    wn[1][k] = ux1 * ic[k] - e.kf * ia[k];
+    wn[2][k] = e.kf * ib[k] - uy0 * ic[k];
+    wn[3][k] = uy1 * ic[k] - e.kf * ib[k];
+    wn[4][k] = ic[k];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    wd[j] = -(wn[j][0] * e.cam[0] + wn[j][1] * e.cam[1] + wn[j][2] * e.cam[2]);
+    wmag[j] = __builtin_fabsf(wn[j][0] * e.cam[0]) + __builtin_fabsf(wn[j][1] * e.cam[1]) + __builtin_fabsf(wn[j][2] * e.cam[2]);   // what wd[j] was summed from
+  }
+}
+// the same planes on the quantized coordinates of a tree: P = m * (q_lo + X * q_scale) + t  (m = NULL: world space, P = q_lo + X q_scale)
+__device__ __forceinline__ void beam_fold(const float wn[5][3], const float wd[5], const float wmag[5], float apex_radius, const float* m, const float* q_lo, const float* q_scale, Plane5& P) {
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    float n0 = wn[j][0], n1 = wn[j][1], n2 = wn[j][2], d = wd[j], mag = wmag[j];
+    if (m) {   // n_obj = M^T n, d_obj = d + n . t
+      const float a0 = wn[j][0] * m[0] + wn[j][1] * m[4] + wn[j][2] * m[8];
+      const float a1 = wn[j][0] * m[1] + wn[j][1] * m[5] + wn[j][2] * m[9];
+      const float a2 = wn[j][0] * m[2] + wn[j][1] * m[6] + wn[j][2] * m[10];
+      d = wd[j] + (wn[j][0] * m[3] + wn[j][1] * m[7] + wn[j][2] * m[11]);
+      mag += __builtin_fabsf(wn[j][0] * m[3]) + __builtin_fabsf(wn[j][1] * m[7]) + __builtin_fabsf(wn[j][2] * m[11]);
+      n0 = a0; n1 = a1; n2 = a2;
+    }
+    const float t0 = n0 * q_lo[0], t1 = n1 * q_lo[1], t2 = n2 * q_lo[2];
+    P.nx[j] = n0 * q_scale[0]; P.ny[j] = n1 * q_scale[1]; P.nz[j] = n2 * q_scale[2];
+    P.d[j] = d + (t0 + t1 + t2);
+    mag += __builtin_fabsf(t0) + __builtin_fabsf(t1) + __builtin_fabsf(t2) + 65535.0f * (__builtin_fabsf(P.nx[j]) + __builtin_fabsf(P.ny[j]) + __builtin_fabsf(P.nz[j]));
+    // >> the rounding of every binary32 step above and of the evaluation below (a few 1e-7 of mag); plus, for rays that only pass
+    // within apex_radius of the view point instead of through it, every plane moved outward by that distance
+    P.slack[j] = 2e-5f * mag + apex_radius * __builtin_sqrtf(wn[j][0] * wn[j][0] + wn[j][1] * wn[j][1] + wn[j][2] * wn[j][2]) * 1.0001f;
+  }
+}
+// can a ray of the beam enter the quantized box (wx, wy, wz)?  key = where the tile's centre ray passes the last of the box's
+// near planes (its entry distance when it hits the box): the order of the entries, the same measure the traversal orders by
+__device__ __forceinline__ bool beam_box(const Plane5& P, uint32_t wx, uint32_t wy, uint32_t wz, float& key) {
+  if ((wx & 0xFFFFu) > (wx >> 16)) return false;   // the absent child of a synthetic single-child root
+  {
+    const uint32_t rx = __builtin_amdgcn_alignbit(wx, wx, P.rot.x), ry = __builtin_amdgcn_alignbit(wy, wy, P.rot.y), rz = __builtin_amdgcn_alignbit(wz, wz, P.rot.z);
+    key = fmaxf(fmaxf(__builtin_fmaf((float)(rx & 0xFFFFu), P.qs.x, P.qb.x), __builtin_fmaf((float)(ry & 0xFFFFu), P.qs.y, P.qb.y)),
+                fmaxf(__builtin_fmaf((float)(rz & 0xFFFFu), P.qs.z, P.qb.z), 0.0f));
+  }
+  const float lx = (float)(wx & 0xFFFFu), hx = (float)(wx >> 16), ly = (float)(wy & 0xFFFFu), hy = (float)(wy >> 16), lz = (float)(wz & 0xFFFFu), hz = (float)(wz >> 16);
+  bool in = true;
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const float mx = P.nx[j] * (P.nx[j] >= 0.0f ? hx : lx) + P.ny[j] * (P.ny[j] >= 0.0f ? hy : ly) + P.nz[j] * (P.nz[j] >= 0.0f ? hz : lz) + P.d[j];
+    in = in && (mx >= -P.slack[j]);
+  }
+  return in;
+}
+
+constexpr int ENTRY_TLAS_CAP = 4;       // TLAS words kept per tile (instances / unopened TLAS nodes)
+constexpr int ENTRY_MAX_ROUNDS = 72;    // levels one tree can be opened (BLAS depth <= 40, TLAS <= 20; whatever is open then is a valid entry set)
+constexpr int ENTRY_FREE = 0x7FFFFFFF;  // an unused slot of a tile's list
+
+// EIGHT LANES PER TILE, one per slot of the tile's list, level-synchronous: in every round each lane that holds an unvisited
+// interior node fetches it and tests both children against the beam (the lanes of a tile work in parallel, so a round costs one
+// node fetch whatever the length of the list: the search is as deep as the tree, ~15 dependent fetches, instead of one per node
+// opened).  No child hit: the slot becomes free.  One: the slot descends.  Two: the lane asks for a free slot of its tile —
+// requests are ranked (the ones waiting longest, i.e. the shallowest nodes, first) against the free slots with two ballots, the
+// second child travels through LDS; a request that finds no room keeps its (unsplit) node, which stays a valid entry.
+// Returns when no lane of the wave has anything left to open.  TLAS: a leaf whose instance the ray mask cannot see is dropped.
+template <bool TLAS>
+__device__ __forceinline__ void entry_open(const SceneDev& sc, const Plane5& P, int& w, float& key, uint32_t cap, int (*s_xw)[8], float (*s_xk)[8]) {
+  const char* const node_bytes = reinterpret_cast<const char*>(sc.blas_nodes);
+  const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, grp = lane >> 3, gsh = lane & 56u;
+  const uint32_t below = (1u << sub) - 1u;
+  bool pend = false, visited = false;   // pend: the node splits (both children stashed) and waits for a free slot
+  int c0 = 0, c1 = 0; float k0 = 0.f, k1 = 0.f;
+  for (int round = 0; round < ENTRY_MAX_ROUNDS; round++) {
+    const bool act = w >= 0 && w != ENTRY_FREE && !visited;
+    const bool old_req = pend;
+    if (act) {
+      const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)w << 5));
+      const uint4 Q0 = np[0], Q1 = np[1];
+      bool h0 = beam_box(P, Q0.x, Q0.y, Q0.z, k0), h1 = beam_box(P, Q0.w, Q1.x, Q1.y, k1);
+      c0 = (int)Q1.z; c1 = (int)Q1.w;
+      if (TLAS) {
+        if (h0 && c0 < 0 && (sc.inst[~c0].mask & 0xFFu) == 0u) h0 = false;
+        if (h1 && c1 < 0 && (sc.inst[~c1].mask & 0xFFu) == 0u) h1 = false;
+      }
+      if (h0 && h1) { pend = true; visited = true; }
+      else if (h0 || h1) { w = h0 ? c0 : c1; key = h0 ? k0 : k1; }   // one child: descend (the new node is unvisited)
+      else w = ENTRY_FREE;
+    }
+    // ---- free slots against split requests, per tile
+    const uint32_t free_m = (uint32_t)(__ballot(w == ENTRY_FREE && sub < cap) >> gsh) & 0xFFu;
+    const uint32_t old_m = (uint32_t)(__ballot(old_req) >> gsh) & 0xFFu, new_m = (uint32_t)(__ballot(pend && !old_req) >> gsh) & 0xFFu;
+    const uint32_t n_free = (uint32_t)__builtin_popcount(free_m);
+    const uint32_t my_req = old_req ? (uint32_t)__builtin_popcount(old_m & below) : (uint32_t)__builtin_popcount(old_m) + (uint32_t)__builtin_popcount(new_m & below);
+    const bool granted = pend && my_req < n_free;
+    const uint32_t n_granted = min(n_free, (uint32_t)__builtin_popcount(old_m | new_m));
+    if (granted) { s_xw[grp][my_req] = c1; s_xk[grp][my_req] = k1; w = c0; key = k0; pend = false; visited = false; }
+    __syncthreads();
+    const uint32_t my_free = (uint32_t)__builtin_popcount(free_m & below);
+    if (w == ENTRY_FREE && sub < cap && my_free < n_granted) { w = s_xw[grp][my_free]; key = s_xk[grp][my_free]; visited = false; }
+    __syncthreads();
+    if (__ballot((w >= 0 && w != ENTRY_FREE && !visited)) == 0ull) break;   // nothing left to open in this wave (grants make unvisited words)
+  }
+}
+
+// one wave = 8 tiles x 8 list slots
+__global__ __launch_bounds__(64) void k_entry(SceneDev sc, EntryViews views) {
+  __shared__ int s_xw[8][8];  __shared__ float s_xk[8][8];   // split exchange / all-to-all of a tile's list
+  const EntryArgs& e = views.v[blockIdx.y];                  // view: 0 the camera, 1..6 the faces of the cube around the light
+  const uint32_t lane = threadIdx.x, sub = lane & 7u, grp = lane >> 3;
+  const uint32_t t = blockIdx.x * 8u + grp;
+  const uint32_t n_tiles = (uint32_t)(e.tiles_x * e.tile_rows);
+  bool work = t < n_tiles;
+  const uint32_t tc = work ? t : 0u;
+  const uint32_t tx = tc % (uint32_t)e.tiles_x, lty = tc / (uint32_t)e.tiles_x;
+  uint32_t fty = lty;   // tile row of the full frame (bands are whole tiles when entry lists are on)
+  if (e.n_shards != 1) {
+    const uint32_t tiles_per_band = (uint32_t)e.band_rows >> 3;
+    const uint32_t band = lty / tiles_per_band, sb = lty - band * tiles_per_band;
+    fty = (band * (uint32_t)e.n_shards + (uint32_t)e.shard) * tiles_per_band + sb;
+  }
+  EntryRec* const rec = e.records + tc;
+  if (work && e.cover != nullptr && e.cover[0] == 0u) {
+    const uint32_t ct = fty * (uint32_t)e.cover_tiles_x + tx;
+    if (((e.cover[1u + (ct >> 5)] >> (ct & 31u)) & 1u) == 0u) {   // no mesh projects onto this tile
+      work = false;
+      if (sub == 0u) rec->w[0] = (int)ENTRY_EMPTY;
+    }
+  }
+  if (__ballot(work) == 0ull) return;   // (wave-uniform: the barriers below are reached by all 64 lanes or by none)
+  // the tile's rectangle of (ux, uy), src/shader.rgen:74-75, with a quarter of a pixel of margin (jitter in [0, 1] after
+  // rounding, binary32 evaluation of ux/uy and of the normalised direction: all far below it)
+  const float m = 0.25f;
+  const float ux0 = 2.0f * ((float)(8u * tx) - m) / (float)e.width - 1.0f, ux1 = 2.0f * ((float)(8u * tx + 8u) + m) / (float)e.width - 1.0f;
+  const float uy1 = 1.0f - 2.0f * ((float)(8u * fty) - m) / (float)e.height, uy0 = 1.0f - 2.0f * ((float)(8u * fty + 8u) + m) / (float)e.height;
+  float wn[5][3], wd[5], wmag[5];
+  beam_world(e, ux0, ux1, uy0, uy1, wn, wd, wmag);
+  Plane5 P;
+  beam_fold(wn, wd, wmag, e.apex_radius, nullptr, sc.tlas_q_lo, sc.tlas_q_scale, P);
+  // the tile's centre ray (direction not normalised: the keys of one tile only have to be comparable with one another)
+  const float uxc = 0.5f * (ux0 + ux1), uyc = 0.5f * (uy0 + uy1);
+  const F3 cam = mk3(e.cam[0], e.cam[1], e.cam[2]);
+  const F3 dc = mk3(uxc * e.basis[0] + uyc * e.basis[3] + e.kf * e.basis[6], uxc * e.basis[1] + uyc * e.basis[4] + e.kf * e.basis[7], uxc * e.basis[2] + uyc * e.basis[5] + e.kf * e.basis[8]);
+  quant_space(cam, dc, sc.tlas_q_lo, sc.tlas_q_scale, P.qs, P.qb, P.rot);
+  // ---- the TLAS: instances (and, beyond ENTRY_TLAS_CAP, unopened TLAS nodes) the beam can touch
+  int w = (work && sub == 0u) ? sc.tlas_root : ENTRY_FREE;
+  float key = 0.0f;
+  entry_open<true>(sc, P, w, key, ENTRY_TLAS_CAP, s_xw, s_xk);
+  // every lane of the tile reads the whole TLAS list and orders it (near first) the same way
+  if (sub < (uint32_t)ENTRY_TLAS_CAP) { s_xw[grp][sub] = w; s_xk[grp][sub] = key; }
+  __syncthreads();
+  int tw[ENTRY_TLAS_CAP]; float tk[ENTRY_TLAS_CAP];
+#pragma unroll
+  for (int i = 0; i < ENTRY_TLAS_CAP; i++) { tw[i] = s_xw[grp][i]; tk[i] = tw[i] == ENTRY_FREE ? 3.0e38f : s_xk[grp][i]; }
+  __syncthreads();
+#define RT_CSWAP(i_, j_) { const bool sw_ = tk[j_] < tk[i_]; const int a_ = sw_ ? tw[j_] : tw[i_], b_ = sw_ ? tw[i_] : tw[j_]; const float ka_ = sw_ ? tk[j_] : tk[i_], kb_ = sw_ ? tk[i_] : tk[j_]; tw[i_] = a_; tw[j_] = b_; tk[i_] = ka_; tk[j_] = kb_; }
+  RT_CSWAP(0, 1) RT_CSWAP(2, 3) RT_CSWAP(0, 2) RT_CSWAP(1, 3) RT_CSWAP(1, 2)
+#undef RT_CSWAP
+  int nt = 0;
+#pragma unroll
+  for (int i = 0; i < ENTRY_TLAS_CAP; i++) nt += tw[i] != ENTRY_FREE ? 1 : 0;
+  // the nearest instance (TLAS leaf) of the list is opened further; the other words stay as they are
+  int ia = -1;
+#pragma unroll
+  for (int i = ENTRY_TLAS_CAP - 1; i >= 0; i--) if (i < nt && tw[i] < 0) ia = i;
+  uint32_t inst = ENTRY_NO_INST;
+  int rest[ENTRY_TLAS_CAP];   // the other words, near first
+  int n_rest = 0;
+#pragma unroll
+  for (int i = 0; i < ENTRY_TLAS_CAP; i++) rest[i] = ENTRY_FREE;
+  {
+    int o = 0;
+#pragma unroll
+    for (int i = 0; i < ENTRY_TLAS_CAP; i++)
+      if (i < nt && i != ia) {
+#pragma unroll
+        for (int j = 0; j < ENTRY_TLAS_CAP; j++) if (j == o) rest[j] = tw[i];
+        o++;
+      }
+    n_rest = o;
+  }
+  // ---- the BLAS of that instance
+  w = ENTRY_FREE; key = 0.0f;
+  uint32_t cap_b = 0;
+  if (work && ia >= 0) {
+    int wa = ENTRY_FREE;
+#pragma unroll
+    for (int i = 0; i < ENTRY_TLAS_CAP; i++) if (i == ia) wa = tw[i];
+    inst = (uint32_t)(~wa);
+    const InstanceDev* I = sc.inst + inst;
+    float o2w[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) o2w[k] = I->o2w[k];
+    beam_fold(wn, wd, wmag, e.apex_radius, o2w, I->q_lo, I->q_scale, P);
+    quant_space(xform_point(I->w2o, cam), xform_vec(I->w2o, dc), I->q_lo, I->q_scale, P.qs, P.qb, P.rot);
+    if (sub == 0u) w = I->blas_root;
+    cap_b = (uint32_t)(ENTRY_WORDS - n_rest);   // stack words: n_rest + REF_MARK + (nb - 1) <= ENTRY_WORDS
+  }
+  entry_open<false>(sc, P, w, key, cap_b, s_xw, s_xk);
+  // rank of this lane's word among the tile's BLAS words (near first; ties by slot)
+  s_xw[grp][sub] = w; s_xk[grp][sub] = key;
+  __syncthreads();
+  int nb = 0, rank = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int wi = s_xw[grp][i]; const float ki = s_xk[grp][i];
+    if (wi != ENTRY_FREE) { nb++; if (w != ENTRY_FREE && (ki < key || (ki == key && (uint32_t)i < sub))) rank++; }
+  }
+  if (!work) return;
+  if (nb == 0) inst = ENTRY_NO_INST;
+  if (nb == 0 && n_rest == 0) { if (sub == 0u) rec->w[0] = (int)ENTRY_EMPTY; return; }
+  // record: w[0] header, w[1] first node, w[2..] stack words bottom first: [rest far -> near] [REF_MARK] [BLAS far -> near]
+  if (nb > 0) {
+    if (w != ENTRY_FREE) rec->w[rank == 0 ? 1 : 2 + n_rest + 1 + (nb - 1 - rank)] = w;
+    if (sub == 0u) {
+#pragma unroll
+      for (int i = 0; i < ENTRY_TLAS_CAP; i++) if (i < n_rest) rec->w[2 + (n_rest - 1 - i)] = rest[i];
+      rec->w[2 + n_rest] = REF_MARK;
+      rec->w[0] = (int)((uint32_t)(n_rest + nb) | ((uint32_t)(n_rest + 1) << 4) | (inst << 8));
+    }
+  } else if (sub == 0u) {
+    rec->w[1] = rest[0];
+#pragma unroll
+    for (int i = 1; i < ENTRY_TLAS_CAP; i++) if (i < n_rest) rec->w[2 + (n_rest - 1 - i)] = rest[i];
+    rec->w[0] = (int)((uint32_t)(n_rest - 1) | ((uint32_t)(n_rest - 1) << 4) | (ENTRY_NO_INST << 8));
+  }
 }
 
 __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u) {
@@ -373,6 +644,9 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
     const uint32_t t = fty * (uint32_t)f.cover_tiles_x + blockIdx.x;
     covered = ((f.cover[1u + (t >> 5)] >> (t & 31u)) & 1u) != 0u;
   }
+  // entry lists (k_entry): the record of this tile says whether its beam touches anything at all
+  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+  if (f.entry != nullptr && covered && (uint32_t)f.entry[tile].w[0] == ENTRY_EMPTY) covered = false;
   bool survive = false;
   F3 d = mk3(0.f, 0.f, 1.f);
   uint32_t sid = 0;
@@ -424,7 +698,8 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   const uint32_t slot = wave_alloc(survive, f.counters + cnt_tail(0, (int)shard));
   if (survive) {
     const uint32_t v = shard * f.shard_cap + slot;
-    f.ray_o[0][v] = make_float4(u.position[0], u.position[1], u.position[2], 10000.0f);
+    // (with entry lists the ray carries its tile instead of tmax, which is the constant 10000 of src/shader.rgen:87)
+    f.ray_o[0][v] = make_float4(u.position[0], u.position[1], u.position[2], f.entry != nullptr ? __uint_as_float(tile) : 10000.0f);
     f.ray_d[0][v] = make_float4(d.x, d.y, d.z, __uint_as_float(sid));
   }
 }
@@ -448,14 +723,14 @@ struct TraceArgs {
   float tmin;
   uint32_t rays_per_lane;      // device-side grid sizing (variant 0): blocks beyond total/(256*rays_per_lane) exit
   uint32_t min_blocks;
+  const EntryRec* entry;       // ENTRY kernels: the tile records of k_entry (closest hit: the ray carries its tile in o.w;
+  const uint32_t* sh_e;        // shadow: record index | ENTRY_REVERSE of every shadow-queue entry, written by k_shade)
 };
 
 constexpr int MODE_CLOSEST = 0;  // pipeline closest hit: o.w = tmax, d.w = sid
 constexpr int MODE_SHADOW = 1;   // pipeline any hit + shading epilogue
 constexpr int MODE_RAW = 2;      // o.w = tmin, d.w = tmax; writes HitRec
 
-constexpr int REF_DONE = (int)0x80000000;   // bottom-of-stack sentinel: the ray is finished
-constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both negative: not interior)
 
 // ---- variant 0: BVH2, ONE LANE PER RAY, persistent threads with per-lane refill.
 //   * 64-ray chunks from the sharded cursors; the next chunk is in flight into registers while the
@@ -479,6 +754,9 @@ constexpr int REF_MARK = (int)0x80000001;   // "leave the instance" marker (both
 #ifndef RT_WIDE_UNROLL
 #define RT_WIDE_UNROLL 1
 #endif
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 5    /* waves per SIMD the shipped traversal kernels are register-allocated for (= workgroups per CU) */
+#endif
 #ifndef RT_STACK2_LDS
 #define RT_STACK2_LDS 12   /* 12 entries in LDS (3 KB per wave) let 6 blocks share a CU; deeper paths spill to HBM */
 #endif
@@ -495,12 +773,13 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 #define PH_END(k)
 #endif
 
-template <int MODE, bool ANY, bool COUNT, bool WIDE>
+template <int MODE, bool ANY, bool COUNT, bool WIDE, bool ENTRY = false>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
+  __shared__ uint32_t s_ent[(ENTRY && MODE == MODE_SHADOW) ? 4 : 1][64];   // entry record of every ray of the current chunk
   // BVH nodes staged through LDS: the first n_hot entries of the node array are the top levels of every BLAS (breadth-first
   // over all meshes, rt_api link_blas) — the nodes nearly every ray visits.  A visit to one of them is two ds_read_b128
   // instead of two divergent 16-byte requests to the CU's vector-memory address unit, which is what bounds this kernel
@@ -546,6 +825,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
   uint32_t pf_base = 0, pf_count = 0;
   float4 pf_o = make_float4(0, 0, 0, 0), pf_d = pf_o;
+  uint32_t pf_e = ENTRY_FROM_ROOT;
   uint32_t chunk_base = 0, chunk_count = 0, chunk_pos = 0;
   auto prefetch = [&]() {
     pf_count = 0;
@@ -559,10 +839,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     }
     if (lane < pf_count) {
       pf_o = a.ray_o[pf_base + lane]; pf_d = a.ray_d[pf_base + lane];
+      if (ENTRY && MODE == MODE_SHADOW) pf_e = a.sh_e[pf_base + lane];
     }
   };
   auto promote = [&]() {
     s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
+    if (ENTRY && MODE == MODE_SHADOW) s_ent[wave][lane] = pf_e;
     chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
     prefetch();
   };
@@ -617,6 +899,28 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     else cur = *reinterpret_cast<volatile int32_t*>(ovf + (sp - STACK2_LDS));   // volatile: never merged with the LDS load into a flat_load
   };
 
+  // ray -> object space of instance ii (t preserved); returns (root of its BLAS, instance mask)
+  auto to_instance = [&](int ii, int& root, uint32_t& imask) {
+    float4 m0, m1, m2, ql, qsc;   // w2o rows, (q_lo, root), (q_scale, mask)
+    if (ii < n_lds_inst) { m0 = s_inst[ii][0]; m1 = s_inst[ii][1]; m2 = s_inst[ii][2]; ql = s_inst[ii][3]; qsc = s_inst[ii][4]; }
+    else {
+      const InstanceDev* I = a.sc.inst + ii;
+      const float4* mp = reinterpret_cast<const float4*>(I->w2o);
+      m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
+      ql = make_float4(I->q_lo[0], I->q_lo[1], I->q_lo[2], __int_as_float(I->blas_root));
+      qsc = make_float4(I->q_scale[0], I->q_scale[1], I->q_scale[2], __uint_as_float(I->mask));
+    }
+    root = __float_as_int(ql.w); imask = __float_as_uint(qsc.w);
+    if ((imask & 0xFFu) != 0u) {
+      float m[12];
+      m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
+      m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
+      co = xform_point(m, wo); cd = xform_vec(m, wd);
+      const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
+      quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
+    }
+  };
+
   for (;;) {
     // ---- (A) refill
     PH_BEGIN(5)
@@ -635,11 +939,51 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           else { tmax = ro.w; sid = __float_as_uint(rd.w); }
           wo = mk3(ro.x, ro.y, ro.z); wd = mk3(rd.x, rd.y, rd.z);
           co = wo; cd = wd;
-          quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
-          best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
           cur_inst = -1;
-          stk[0] = REF_DONE; sp = 1;
-          cur = a.sc.tlas_root;   // TLAS root (always interior)
+          stk[0] = REF_DONE;
+          if (ENTRY) {
+            // the walk starts at the record of the ray's tile (k_entry): its words go on the stack, its first node becomes the
+            // current one, and the ray enters the record's instance here instead of in phase (C)
+            uint32_t ent;
+            if (MODE == MODE_SHADOW) ent = s_ent[wave][ci];
+            else { ent = __float_as_uint(ro.w); tmax = 10000.0f; }   // src/shader.rgen:87 (o.w carries the tile)
+            const bool rev_flag = (ent & ENTRY_REVERSE) != 0u;
+            ent &= ~ENTRY_REVERSE;
+            int4 r0 = make_int4((int)ENTRY_EMPTY, REF_DONE, 0, 0), r1 = make_int4(0, 0, 0, 0);
+            if (ent != ENTRY_FROM_ROOT) {
+              const int4* rp = reinterpret_cast<const int4*>(a.entry + ent);
+              r0 = rp[0]; r1 = rp[1];
+            }
+            const uint32_t hdr = (uint32_t)r0.x;
+            if (ent == ENTRY_FROM_ROOT) {
+              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+              sp = 1; cur = a.sc.tlas_root;
+            } else if (hdr == ENTRY_EMPTY) {
+              sp = 1; cur = REF_DONE;   // nothing a ray of this tile can hit: the ray is finished (a miss)
+            } else {
+              const uint32_t nw = hdr & 15u, n_rm = (hdr >> 4) & 15u, ia = hdr >> 8;
+              // ENTRY_REVERSE: the instance's subtrees in the opposite order (the farthest from the view point first)
+              const bool rev = rev_flag && nw > n_rm;
+              int cur_new = r0.y;
+              const int wk[6] = {r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+              for (uint32_t k = 0; k < 6u; k++)
+                if (k < nw) {
+                  if (rev && k == n_rm) cur_new = wk[k];
+                  else stk[((!rev || k < n_rm) ? 1u + k : 1u + nw + n_rm - k) * 64u] = wk[k];
+                }
+              if (rev) stk[(1u + n_rm) * 64u] = r0.y;
+              sp = 1 + (int)nw;
+              cur = cur_new;
+              if (ia != ENTRY_NO_INST) { int root; uint32_t imask; to_instance((int)ia, root, imask); cur_inst = (int)ia; }   // (k_entry never names an invisible instance)
+              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+            }
+          } else {
+            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+            sp = 1;
+            cur = a.sc.tlas_root;   // TLAS root (always interior)
+          }
+          best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
           need = false;
         }
         chunk_pos += n_need < avail ? n_need : avail;
@@ -815,27 +1159,14 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     if (cur < 0 && cur > REF_MARK && cur_inst < 0) {
       // TLAS leaf: enter the instance (ray -> object space, t preserved)
       const int ii = ~cur;
-      float4 m0, m1, m2, ql, qsc;   // w2o rows, (q_lo, root), (q_scale, mask)
-      if (ii < n_lds_inst) { m0 = s_inst[ii][0]; m1 = s_inst[ii][1]; m2 = s_inst[ii][2]; ql = s_inst[ii][3]; qsc = s_inst[ii][4]; }
-      else {
-        const InstanceDev* I = a.sc.inst + ii;
-        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
-        m0 = mp[0]; m1 = mp[1]; m2 = mp[2];
-        ql = make_float4(I->q_lo[0], I->q_lo[1], I->q_lo[2], __int_as_float(I->blas_root));
-        qsc = make_float4(I->q_scale[0], I->q_scale[1], I->q_scale[2], __uint_as_float(I->mask));
-      }
-      if ((__float_as_uint(qsc.w) & 0xFFu) == 0u) {
+      int root; uint32_t imask;
+      to_instance(ii, root, imask);
+      if ((imask & 0xFFu) == 0u) {
         pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
         if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
       } else {
-        float m[12];
-        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
-        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
-        co = xform_point(m, wo); cd = xform_vec(m, wd);
-        const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
-        quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
         push(REF_MARK);
-        cur_inst = ii; cur = __float_as_int(ql.w);
+        cur_inst = ii; cur = root;
       }
     }
 
@@ -882,8 +1213,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   }
 }
 
-template <int MODE, bool ANY, bool COUNT, bool WIDE>
-__global__ __launch_bounds__(256) void k_trace(TraceArgs a) { trace_body<MODE, ANY, COUNT, WIDE>(a); }
+// (five 256-thread workgroups per CU = five waves per SIMD is what the LDS admits: the register allocator of the shipped kernels
+// is held to that; the instrumented ones (k_trace_count) may take more registers rather than spill — a spill reload would
+// distort the very phase timings they exist to measure)
+template <int MODE, bool ANY, bool WIDE, bool ENTRY = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU))) void k_trace(TraceArgs a) { trace_body<MODE, ANY, false, WIDE, ENTRY>(a); }
+template <int MODE, bool ANY, bool WIDE, bool ENTRY = false>
+__global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY>(a); }
 
 // ---- variant 1: quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
 // 64-lane wavefront.
@@ -1186,6 +1522,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
     bool push_next = false, push_shadow = false;
     F3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     float sh_tmax = 0.f; F3 sh_c = mk3(0, 0, 0); float sh_w = 0.f;
+    uint32_t sh_ent = ENTRY_FROM_ROOT;
     uint32_t sid = SID_DEAD;
     if (base + lane < n) {
       const float4 rd = f.ray_d[cur][q];
@@ -1247,6 +1584,23 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
             sh_c = fma3(w, add3(diff, spec), ambient_of(a.sc, mat)); sh_w = __uint_as_float(mat);
             nd = L; sh_tmax = dist;
             push_shadow = true;
+            if (f.light_entry != nullptr) {
+              // which tile of the cube around the light does this ray belong to?  Seen from the light the ray's ORIGIN lies in
+              // direction v; the ray then runs to within 0.01 of the light (k_entry's beams are widened by that much).
+              const F3 v = sub3(no, mk3(U.light_position[0], U.light_position[1], U.light_position[2]));
+              const float ax = __builtin_fabsf(v.x), ay = __builtin_fabsf(v.y), az = __builtin_fabsf(v.z);
+              const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+              const float vc = axis == 0 ? v.x : (axis == 1 ? v.y : v.z), va = axis == 0 ? v.y : (axis == 1 ? v.z : v.x), vb = axis == 0 ? v.z : (axis == 1 ? v.x : v.y);
+              const float c = __builtin_fabsf(vc);
+              if (c > 0.0f) {
+                const float T8 = (float)(8 * f.light_tiles);
+                const float px = (va / c + 1.0f) * 0.5f * T8, py = (1.0f - vb / c) * 0.5f * T8;
+                const int tx = min(max((int)(px * 0.125f), 0), f.light_tiles - 1), ty = min(max((int)(py * 0.125f), 0), f.light_tiles - 1);
+                const int face = 2 * axis + (vc < 0.0f ? 1 : 0);
+                // a surface that faces away from the light is almost always shadowed by its own neighbourhood: start there
+                sh_ent = (uint32_t)((face * f.light_tiles + ty) * f.light_tiles + tx) | (NdotL < 0.0f ? ENTRY_REVERSE : 0u);
+              }
+            }
           }
         } else if (type == 1u) {
           // src/shader.rgen:132-138
@@ -1292,6 +1646,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
       f.sh_o[v] = make_float4(no.x, no.y, no.z, sh_tmax);
       f.sh_d[v] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
       f.sh_c[v] = make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w);
+      if (f.sh_e != nullptr) f.sh_e[v] = sh_ent;
     }
   }
 }
@@ -1438,9 +1793,9 @@ void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, 
   hipLaunchKernelGGL(k_raygen, g, b, 0, s, sc, f, u);
 }
 
-void launch_cover(const SceneDev& sc, const CoverArgs& a, uint32_t max_boxes_per_instance, uint32_t* mask, hipStream_t s) {
-  if (a.n_inst <= 0 || max_boxes_per_instance == 0) return;
-  hipLaunchKernelGGL(k_cover, dim3((max_boxes_per_instance + 255u) / 256u, (unsigned)a.n_inst), dim3(256), 0, s, sc, a, mask);
+void launch_cover(const SceneDev& sc, const CoverViews& a, uint32_t max_boxes_per_instance, uint32_t* mask_block, hipStream_t s) {
+  if (a.n <= 0 || a.v[0].n_inst <= 0 || max_boxes_per_instance == 0) return;
+  hipLaunchKernelGGL(k_cover, dim3((max_boxes_per_instance + 255u) / 256u, (unsigned)a.v[0].n_inst, (unsigned)a.n), dim3(256), 0, s, sc, a, mask_block);
 }
 
 static TraceArgs make_args(const SceneDev& sc, uint32_t* counters, int queue, uint32_t shard_cap, int32_t* ovf) {
@@ -1462,11 +1817,11 @@ static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& 
   a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
   const dim3 g(cfg.trace_blocks), b(256);
   if (cfg.variant == 0) {
-    if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE, ANY, false, false>), g, b, 0, s, a);
+    if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, false>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE, ANY, false>), g, b, 0, s, a);
   } else if (cfg.variant == 2) {
-    if (counting) hipLaunchKernelGGL((k_trace<MODE, ANY, true, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE, ANY, false, true>), g, b, 0, s, a);
+    if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE, ANY, true>), g, b, 0, s, a);
   } else {
     if (counting) hipLaunchKernelGGL((k_trace4<MODE, ANY, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace4<MODE, ANY, false>), g, b, 0, s, a);
@@ -1477,13 +1832,38 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
   TraceArgs a = make_args(sc, f.counters, bounce, f.shard_cap, f.ovf_stack);
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
+  if (bounce == 0 && f.entry != nullptr && cfg.variant == 0) {
+    // primary rays start at their tile's entry record (k_entry)
+    a.entry = f.entry;
+    a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
+    const dim3 g(cfg.trace_blocks), b(256);
+    if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true>), g, b, 0, s, a);
+    return;
+  }
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
+}
+
+void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s) {
+  uint32_t n = 0;
+  for (int v = 0; v < a.n; v++) n = max(n, (uint32_t)(a.v[v].tiles_x * a.v[v].tile_rows));
+  if (n == 0) return;
+  hipLaunchKernelGGL(k_entry, dim3((n + 7u) / 8u, (unsigned)a.n), dim3(64), 0, s, sc, a);   // 8 lanes per tile; blockIdx.y = view
 }
 
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, f.counters, Q_SHADOW, f.shard_cap, f.ovf_stack);
   a.ray_o = f.sh_o; a.ray_d = f.sh_d; a.sh_c = f.sh_c;
   a.sample_color = f.sample_color;
+  if (f.light_entry != nullptr && f.sh_e != nullptr && cfg.variant == 0) {
+    // shadow rays start at the record of their tile of the cube around the light (k_entry, k_shade)
+    a.entry = f.light_entry; a.sh_e = f.sh_e;
+    a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
+    const dim3 g(cfg.trace_blocks), b(256);
+    if (counting) hipLaunchKernelGGL((k_trace_count<MODE_SHADOW, true, false, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE_SHADOW, true, false, true>), g, b, 0, s, a);
+    return;
+  }
   launch_trace<MODE_SHADOW, true>(a, counting, cfg, s);
 }
 

@@ -157,6 +157,13 @@ struct rt_ctx {
   int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
   int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
   bool tail_full_grid = false;
+  int entry_points = 1;          // 1: k_entry gives every covered tile a list of deep subtrees and its primary rays start there (result-identical)
+  int shadow_entry = 1;          // 1: ... and every tile of a cube around the light one for the shadow rays (needs entry_points)
+  int light_tiles = LIGHT_TILES_DEFAULT;   // tiles per side of a face of that cube
+  EntryRec* d_entry = nullptr;   // one record per 8x8 tile of this slot's largest frame so far
+  size_t entry_alloc_tiles = 0;
+  EntryRec* d_light_entry = nullptr;   // 6 * light_tiles^2 records
+  size_t light_alloc_tiles = 0;
   uint32_t* d_cover_mask = nullptr;   // TWO masks of cover_alloc_words: frame k uses one, its k_resolve clears the other
   uint32_t cover_alloc_words = 0;
   int cover_parity = 0;
@@ -579,9 +586,11 @@ int ensure_frame(rt_ctx* c, size_t capacity) {
                    (void**)&f.sh_o, (void**)&f.sh_d, (void**)&f.sh_c, (void**)&f.sample_color};
   for (void** p : ptrs) { if (*p) HIP_TRY(c, hipFree(*p)); *p = nullptr; }
   if (f.hit_inst) { HIP_TRY(c, hipFree(f.hit_inst)); f.hit_inst = nullptr; }
+  if (f.sh_e) { HIP_TRY(c, hipFree(f.sh_e)); f.sh_e = nullptr; }
   c->frame_capacity = 0;
   for (void** p : ptrs) HIP_TRY(c, hipMalloc(p, capacity * sizeof(float4)));
   HIP_TRY(c, hipMalloc((void**)&f.hit_inst, capacity * sizeof(int32_t)));
+  HIP_TRY(c, hipMalloc((void**)&f.sh_e, capacity * sizeof(uint32_t)));
   c->frame_capacity = capacity;
   return RT_OK;
 }
@@ -629,7 +638,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   const SceneDev sc = scene_dev(c);
   // Primary-ray coverage mask: on when the bands are whole 8x8 tiles, the camera basis is invertible and the scene has boxes.
   // The mask of this frame was cleared by the previous frame's k_resolve (or at allocation); this frame's clears the other.
-  CoverArgs ca{};
+  // Views: 0 = the camera; 1..6 = the faces of a cube around the light, when the shadow rays take entry lists (below).
+  CoverViews cv{};
+  CoverArgs& ca = cv.v[0];
   bool cover_on = c->primary_cover && rows > 0 && c->scene->max_cover_count > 0 && (n_shards == 1 || band_rows % 8 == 0) && c->cfg.variant != 1 &&
                   c->h_inst.size() <= 65535;   // (k_cover's grid has one row of workgroups per instance)
   if (cover_on) {
@@ -644,13 +655,23 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
                              (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
       for (int k = 0; k < 9; k++) ca.inv[k] = (float)inv[k];
       for (int k = 0; k < 3; k++) ca.cam[k] = u.position[k];
+      ca.kf = 2.5f;   // src/shader.rgen:79
       ca.width = W; ca.height = H; ca.tiles_x = (W + 7) / 8; ca.tiles_y = (H + 7) / 8; ca.n_inst = (int)c->h_inst.size();
+      ca.mask_offset = 0; ca.apex_radius = 0.0f;
+      cv.n = 1;
     }
   }
+  // Entry lists (k_entry) ride on the coverage mask: same tiles, same camera basis; the one-lane BVH2 kernel only.
+  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && c->h_inst.size() < ENTRY_NO_INST;
+  // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
+  const bool light_on = entry_on && c->shadow_entry && std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2]);
+  const int LT = c->light_tiles;
+  const uint32_t cam_words = 1u + (uint32_t)((((size_t)((W + 7) / 8) * (size_t)((H + 7) / 8)) + 31) / 32);
+  const uint32_t face_words = 1u + (uint32_t)(((size_t)LT * LT + 31) / 32);
   {
-    const uint32_t words = 1u + (uint32_t)((((size_t)((W + 7) / 8) * (size_t)((H + 7) / 8)) + 31) / 32);
+    const uint32_t words = cam_words + 6u * face_words;
     if (cover_on && words > c->cover_alloc_words) {
-      if (c->d_cover_mask) { HIP_TRY(c, hipStreamSynchronize(c->stream)); HIP_TRY(c, hipFree(c->d_cover_mask)); c->d_cover_mask = nullptr; c->cover_alloc_words = 0; }
+      if (c->d_cover_mask) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_cover_mask)); c->d_cover_mask = nullptr; c->cover_alloc_words = 0; }
       HIP_TRY(c, hipMalloc((void**)&c->d_cover_mask, 2 * (size_t)words * sizeof(uint32_t)));
       HIP_TRY(c, hipMemsetAsync(c->d_cover_mask, 0, 2 * (size_t)words * sizeof(uint32_t), c->stream));
       HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -662,6 +683,55 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     f.cover = cover_on ? c->d_cover_mask + (size_t)c->cover_parity * c->cover_alloc_words : nullptr;
     f.cover_next = c->d_cover_mask + (size_t)(c->cover_parity ^ 1) * c->cover_alloc_words;
     f.cover_words = c->cover_alloc_words; f.cover_tiles_x = (W + 7) / 8;
+  }
+  EntryViews ev{};
+  if (entry_on && f.cover != nullptr) {
+    const size_t tiles_local = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
+    if (tiles_local > c->entry_alloc_tiles) {
+      if (c->d_entry) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_entry)); c->d_entry = nullptr; c->entry_alloc_tiles = 0; }
+      HIP_TRY(c, hipMalloc((void**)&c->d_entry, tiles_local * sizeof(EntryRec)));
+      c->entry_alloc_tiles = tiles_local;
+    }
+    f.entry = c->d_entry;
+    EntryArgs& ea = ev.v[0];
+    for (int k = 0; k < 3; k++) ea.cam[k] = ca.cam[k];
+    for (int k = 0; k < 9; k++) ea.inv[k] = ca.inv[k];
+    for (int k = 0; k < 3; k++) { ea.basis[k] = u.right[k]; ea.basis[3 + k] = u.up[k]; ea.basis[6 + k] = u.forward[k]; }
+    ea.kf = 2.5f; ea.apex_radius = 0.0f;
+    ea.width = W; ea.height = H; ea.tiles_x = (W + 7) / 8; ea.tile_rows = (rows + 7) / 8;
+    ea.band_rows = band_rows; ea.shard = shard; ea.n_shards = n_shards;
+    ea.records = c->d_entry; ea.cover = f.cover; ea.cover_tiles_x = f.cover_tiles_x;
+    ev.n = 1;
+    if (light_on) {
+      const size_t light_tiles_total = (size_t)6 * LT * LT;
+      if (light_tiles_total > c->light_alloc_tiles) {
+        if (c->d_light_entry) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_light_entry)); c->d_light_entry = nullptr; c->light_alloc_tiles = 0; }
+        HIP_TRY(c, hipMalloc((void**)&c->d_light_entry, light_tiles_total * sizeof(EntryRec)));
+        c->light_alloc_tiles = light_tiles_total;
+      }
+      f.light_entry = c->d_light_entry; f.light_tiles = LT;   // (f.sh_e: allocated with the ray queues)
+      // a shadow ray starts 0.01 N off the shaded point and runs parallel to the line from that point to the light
+      // (src/shader.rgen:107-110): it ends within 0.01 (+ rounding) of the light, not in it
+      const float apex_radius = 0.0102f;
+      for (int face = 0; face < 6; face++) {
+        const int axis = face >> 1, a1 = (axis + 1) % 3, a2 = (axis + 2) % 3;
+        const float sgn = (face & 1) ? -1.0f : 1.0f;
+        float basis[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        basis[a1] = 1.0f; basis[3 + a2] = 1.0f; basis[6 + axis] = sgn;   // R, U, F; orthonormal: the inverse is the transpose (rows R, U, F)
+        CoverArgs& lc = cv.v[1 + face];
+        EntryArgs& le = ev.v[1 + face];
+        for (int k = 0; k < 3; k++) lc.cam[k] = le.cam[k] = u.light_position[k];
+        for (int k = 0; k < 9; k++) { lc.inv[k] = le.inv[k] = basis[k]; le.basis[k] = basis[k]; }
+        lc.kf = le.kf = 1.0f; lc.apex_radius = le.apex_radius = apex_radius;
+        lc.width = lc.height = le.width = le.height = 8 * LT;
+        lc.tiles_x = lc.tiles_y = LT; lc.n_inst = ca.n_inst;
+        lc.mask_offset = cam_words + (uint32_t)face * face_words;
+        le.tiles_x = le.tile_rows = LT; le.band_rows = 8 * LT; le.shard = 0; le.n_shards = 1;
+        le.records = c->d_light_entry + (size_t)face * LT * LT;
+        le.cover = f.cover + lc.mask_offset; le.cover_tiles_x = LT;
+      }
+      cv.n = ENTRY_VIEWS; ev.n = ENTRY_VIEWS;
+    }
   }
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
@@ -680,7 +750,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     Span frame_span(c, CAT_FRAME, s);
     {
       Span sp(c, CAT_RAYGEN, s);
-      if (f.cover) launch_cover(sc, ca, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
+      if (f.cover) launch_cover(sc, cv, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
+      if (f.entry) launch_entry(sc, ev, s);
       launch_raygen(sc, f, u, s);
     }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
@@ -851,7 +922,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->out_rgba8 = parent->out_rgba8;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -878,7 +949,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask,
+  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
@@ -1163,6 +1234,13 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     c->out_rgba8 = value != 0; return RT_OK;
   }
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
+  if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
+  if (k == "shadow_entry") { c->shadow_entry = value != 0; return RT_OK; }
+  if (k == "light_tiles") {
+    if (value < 8 || value > 512) return fail(c, RT_ERR_INVALID_ARGUMENT, "light_tiles must be 8..512");
+    { int q = quiesce(c); if (q) return q; }
+    c->light_tiles = value; return RT_OK;
+  }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
   if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); for (rt_ctx* m : c->scene->members) m->blas_builder = value; return RT_OK; }

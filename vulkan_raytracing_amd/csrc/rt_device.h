@@ -130,6 +130,20 @@ constexpr uint32_t MATERIAL_NONE = 0xFFFFFFFFu;          // shadow-queue tag: th
 // nodes; a box whose screen rectangle spans more tiles than COVER_MAX_TILES marks the whole frame instead.
 constexpr int COVER_TARGET_BOXES = 1024;
 constexpr int COVER_MAX_TILES = 4096;
+// Entry lists (k_entry): one 32-byte record per tile of a VIEW — view 0 is the camera (8x8-pixel tiles of the frame: all primary
+// rays leave the camera), views 1..6 are the faces of a cube around the light (all shadow rays END at the light,
+// src/shader.rgen:107-112), each face LIGHT_TILES x LIGHT_TILES tiles.  See kernels.hip.
+//   w[0] = stack words (bits 0-3) | words below the instance's BLAS words, marker included (bits 4-7) | instance << 8
+//   w[1] = first node to visit, w[2..] = the stack words, bottom first
+constexpr int ENTRY_WORDS = 6;                       // stack words a record can hold besides the first node to visit
+constexpr uint32_t ENTRY_EMPTY = 0xFFFFFFFFu;        // w[0]: no ray of the tile can hit anything
+constexpr uint32_t ENTRY_NO_INST = 0xFFFFFFu;        // w[0] >> 8: the rays of the tile start in world space (TLAS words only)
+constexpr uint32_t ENTRY_FROM_ROOT = 0x7FFFFFFFu;    // per-ray record index: none, the walk starts at the TLAS root
+constexpr uint32_t ENTRY_REVERSE = 0x80000000u;      // per-ray flag: take the instance's subtrees far (from the view point) first
+struct alignas(16) EntryRec { int32_t w[2 + ENTRY_WORDS]; };
+static_assert(sizeof(EntryRec) == 32, "EntryRec must be 32 bytes");
+constexpr int ENTRY_VIEWS = 7;                       // camera + 6 light faces
+constexpr int LIGHT_TILES_DEFAULT = 128;             // tiles per side of a light face (rt_set_param "light_tiles")
 constexpr int N_SHARDS = 8;
 constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: one 128-byte line each
 constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounceCount <= 69)

@@ -57,6 +57,14 @@ struct FrameDev {
   uint32_t* cover_next;
   uint32_t cover_words;
   int cover_tiles_x;
+  // Entry lists of this frame's primary rays (NULL: off): record of local tile ty * tiles_x + tx, written by k_entry, read by
+  // k_raygen (empty tiles) and by the closest-hit launch of bounce 0 (where the tile's rays start their walk).
+  EntryRec* entry;
+  // Entry lists of the shadow rays (NULL: off): record ((face * light_tiles) + ty) * light_tiles + tx of the cube around the
+  // light; k_shade gives every shadow ray its record index (sh_e), the shadow traversal starts there.
+  const EntryRec* light_entry;
+  uint32_t* sh_e;              // shadow queue: record index | ENTRY_REVERSE, or ENTRY_FROM_ROOT
+  int light_tiles;
 };
 
 // camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
@@ -64,9 +72,31 @@ struct FrameDev {
 struct CoverArgs {
   float cam[3];
   float inv[9];
+  float kf;                    // 2.5 for the camera (src/shader.rgen:79), 1 for a face of the light cube
+  float apex_radius;           // rays pass within this distance of cam (see EntryArgs)
   int width, height, tiles_x, tiles_y;
   int n_inst;
+  uint32_t mask_offset;        // words from the start of the frame's mask block to this view's mask (word 0: everything marked)
 };
+struct CoverViews { CoverArgs v[ENTRY_VIEWS]; int n; };
+
+// beam of a tile (k_entry): apex cam, directions ux * R + uy * U + kf * F with (a, b, c) = inv * (P - cam) the coordinates of a
+// point in the basis (R, U, F); the camera: R, U, F = right, up, forward, kf = 2.5 (src/shader.rgen:79)
+struct EntryArgs {
+  float cam[3];
+  float inv[9];
+  float basis[9];              // R, U, F (three vectors): the centre ray of a tile orders its entries
+  float kf;
+  float apex_radius;           // the rays pass within this distance of cam (0: through it).  Shadow rays start 0.01 N off the surface
+                               // point whose direction to the light they take (src/shader.rgen:107-110), so they end 0.01 N off the light
+  int width, height;           // full frame
+  int tiles_x, tile_rows;      // local tile grid of this shard (= the grid of k_raygen)
+  int band_rows, shard, n_shards;
+  EntryRec* records;
+  const uint32_t* cover;       // coverage mask of this view (tiles it leaves unmarked get an empty record)
+  int cover_tiles_x;
+};
+struct EntryViews { EntryArgs v[ENTRY_VIEWS]; int n; };
 
 struct LaunchCfg {
   int trace_blocks;            // persistent grid of the traversal kernels (256 threads each)
@@ -78,14 +108,17 @@ struct LaunchCfg {
 
 size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
+// bounce 0 of a frame with entry lists (f.entry) starts every ray at its tile's record
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
+// one lane per tile of the shard: the record of every tile the coverage mask marks
+void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s);
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
 void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
 // marks the tiles of `mask` (FrameDev::cover layout) that the frontier boxes of the instances project onto
-void launch_cover(const SceneDev& sc, const CoverArgs& a, uint32_t max_boxes_per_instance, uint32_t* mask, hipStream_t s);
+void launch_cover(const SceneDev& sc, const CoverViews& a, uint32_t max_boxes_per_instance, uint32_t* mask_block, hipStream_t s);
 // record-level traceRayEXT on raw rays: o = (o.xyz, tmin), d = (d.xyz, tmax); writes HitRec[n]
 // counters must hold the ray count in cnt_tail(0, 0) and zeros elsewhere; rays form shard 0 of capacity shard_cap
 void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, uint32_t shard_cap,
