@@ -261,6 +261,102 @@ class Rig:
             c.close()
 
 
+def main_multi(args):
+    """--host multi: ONE process drives all N GPUs through librt_multi.so (include/rt_multi.h: a scene + P frame slots per
+    device, rt_trace_shard on every device, ONE RCCL gather per frame to the first device, the de-interleave there) — two
+    ctypes calls per step (rtm_trace_async / rtm_trace_wait) are all the Python on the data path.  The assembled frames stay
+    in the root GPU's HBM ("host_copy" 0), as in the one-process-per-GPU mode; --loopback: N logical devices on cuda:0."""
+    from vulkan_raytracing_amd import multi
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the ray-tracing stage has no CPU path")
+    n = args.gpus
+    if not args.loopback and torch.cuda.device_count() < n:
+        raise SystemExit("bench.py --host multi --gpus %d: only %d device(s) visible (use --loopback to rehearse on one GPU)" % (n, torch.cuda.device_count()))
+    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else 16)
+    if args.loopback:
+        P = min(P, max(1, 16 // n))     # all logical devices share one GPU: at most 16 frame slots on it take k_tail's full grid
+    res = os.path.join(ROOT, "resources")
+    host.armadillo_path(res, kind=args.mesh)
+    wl = workloads.make(args.workload, res, mesh=args.mesh)
+    W, H = wl.width, wl.height
+    m = multi.RtMulti([0] * n if args.loopback else list(range(n)), P, loopback=args.loopback)
+    if args.variant is not None:
+        m.set_param("trace_variant", args.variant)
+    wl.apply(m)
+    for kv in args.param:
+        k, v = kv.split("=")
+        m.set_param(k, int(v))
+    m.set_param("host_copy", 1 if args.save_image else 0)
+    time_param = np.float32(0.0)
+
+    def run(steps, animate):
+        nonlocal time_param
+        pending = [False] * P
+        last = None
+        for i in range(steps):
+            j = i % P
+            if pending[j]:
+                last = m.trace_wait(j, copy=False)
+            if animate:
+                time_param = np.float32(time_param + np.float32(ANIM_DT) * np.float32(0.1))
+                m.set_instances(wl.animate(time_param), update=True, slot=j)
+                m.set_uniforms(wl.uniforms, slot=j)
+            m.trace_async(j, W, H)
+            pending[j] = True
+        for k in range(1, P + 1):
+            j = (steps - 1 + k) % P
+            if pending[j]:
+                last = m.trace_wait(j, copy=False)
+        return last
+
+    run(P, False)                      # set-up: every slot allocates its queues
+    run(args.warmup, args.animate)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    px, st = run(args.steps, args.animate)
+    dt = time.perf_counter() - t0      # every frame collected: rtm_trace_wait waits for the devices and for the root's gather + de-interleave
+    anim_ms = anim_rays = None
+    if not args.no_extras and not args.animate:
+        run(max(P, args.warmup), True)
+        t0 = time.perf_counter()
+        _, sta = run(args.steps, True)
+        anim_ms = (time.perf_counter() - t0) / args.steps * 1e3
+        anim_rays = sta.rays_total
+        m.set_instances(wl.instances)
+    ms_step = dt / args.steps * 1e3
+    mb = int(wl.uniforms[0]["max_bounce_count"])
+    metric = "Mrays/sec (primary+secondary+shadow) at %dx%d depth %d" % (W, H, mb + 1)
+    if args.workload == "cfg3":
+        try:
+            metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+        except Exception:
+            pass
+    result = {"metric": metric, "value": st.rays_total * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+              "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "animated_ms_per_step": anim_ms, "animated_value": (anim_rays / anim_ms / 1e3) if anim_ms else None,
+              "config": {"workload": wl.describe() + (" [animated loop timed]" if args.animate else ""), "mesh": wl.mesh_label,
+                         "rays_per_frame": {"primary": st.rays_primary, "secondary": st.rays_secondary, "shadow": st.rays_shadow},
+                         "parallelism": "ONE host process, librt_multi.so: interleaved %d-row bands over %d %s, one scene per device, one %s per frame, "
+                                        "%d frame slots in flight per device" % (tiling.BAND_ROWS, n, "logical devices on one GPU (loopback)" if args.loopback else "GPUs",
+                                                                                 "device-to-device copy" if args.loopback else "RCCL gather (ncclGather in one group)", P),
+                         "frames_in_flight": P, "host": "multi"},
+              "roofline": None, "cpu_baseline": None,
+              "note": "roofline / cpu_baseline are reported by the N = 1 run (python3 bench.py); this line is the N-GPU throughput of the one-process host"}
+    if args.save_image and px is not None:
+        img = np.array(px, dtype=np.float32)
+        with open(args.save_image, "wb") as fh:
+            fh.write(b"PF4\n%d %d\n-1.0\n" % (W, H))
+            fh.write(img[::-1].astype("<f4").tobytes())
+    m.close()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(result), flush=True)
+    os.dup2(2, 1)
+
+
 def main(args):
     # stdout carries exactly one JSON line: library banners (RCCL prints its version to fd 1) go to stderr
     sys.stdout.flush()
@@ -534,4 +630,9 @@ def main(args):
 
 
 if __name__ == "__main__":
-    main(ARGS)
+    if ARGS.host == "multi" and ARGS.gpus > 1:
+        if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            raise SystemExit("bench.py --host multi drives every GPU from ONE process: start it without a launcher (python3 bench.py --gpus N --host multi)")
+        main_multi(ARGS)
+    else:
+        main(ARGS)

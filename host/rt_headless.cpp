@@ -6,7 +6,7 @@
 //
 //   rt_headless [--width W] [--height H] [--frames N] [--dt SECONDS] [--bounce B] [--spp S]
 //               [--center OBJ] [--orbiting OBJ] [--center-type T] [--orbiting-type T]
-//               [--skybox DIR] [--out PREFIX] [--device D] [--frames-in-flight P] [--rgba8]
+//               [--skybox DIR] [--out PREFIX] [--device D] [--frames-in-flight P] [--rgba8 | --bgra8]
 //               [--gpus N [--loopback]]   N GPUs of this node in one process: band sharding + RCCL gather (include/rt_multi.h);
 //                                         --loopback = N logical devices on GPU D, shards moved by device copies (no RCCL)
 #include <chrono>
@@ -53,7 +53,7 @@ static void writePPM(const std::string& path, const std::vector<float>& rgba, in
 int main(int argc, char** argv) {
   int W = 800, H = 600;  // the reference's window size (src/main.cpp:805)
   int frames = 3, device = 0, inFlight = 1, gpus = 0, blocksPerCu = 0;
-  bool rgba8 = false, loopback = false;
+  bool rgba8 = false, bgra8 = false, loopback = false;
   float dt = 1.0f / 60.0f;
   std::string center = CENTER_MESH_OBJ_PATH, orbiting = ORBITING_MESH_OBJ_PATH, skyDir = SKYBOX_TEXTURE_DIR, out = "frame";
   rt_uniforms uniformStructure = rthost::defaultUniforms();
@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
     else if (a == "--gpus") gpus = atoi(next());
     else if (a == "--blocks-per-cu") blocksPerCu = atoi(next());   // persistent traversal grid (experiments; 0 = the library's choice)
     else if (a == "--loopback") loopback = true;
+    else if (a == "--bgra8") { rgba8 = true; bgra8 = true; }   // ... in the byte order of a B8G8R8A8 surface (surfaceFormatList[0], src/main.cpp:1204): <out>.bgra holds the raw bytes
     else if (a == "--rgba8") rgba8 = true;   // frames come back in the 8-bit surface format the reference presents (src/main.cpp:1899); needs --frames-in-flight > 1
     else if (a == "--frames-in-flight") inFlight = std::max(1, atoi(next()));   // the reference: swapchain image count, src/main.cpp:1203
     else { fprintf(stderr, "unknown option %s\n", a.c_str()); return 2; }
@@ -119,7 +120,7 @@ int main(int argc, char** argv) {
       const uint8_t* fp[6];
       for (int f = 0; f < 6; f++) fp[f] = sky[f].data();
       check(rtm_set_skybox(multi, fp, sw, sh), "rtm_set_skybox", multi);
-      if (rgba8) check(rtm_set_param(multi, "output_rgba8", 1), "rtm_set_param", multi);
+      if (rgba8) check(rtm_set_param(multi, bgra8 ? "output_bgra8" : "output_rgba8", 1), "rtm_set_param", multi);
       rthost::SceneAnimation animation;
       auto instances = [&]() {
         std::vector<rt_instance> inst(2);
@@ -165,7 +166,7 @@ int main(int argc, char** argv) {
         f << "P6\n" << W << " " << H << "\n255\n";
         std::vector<unsigned char> row((size_t)W * 3);
         for (int y = 0; y < H; y++) {
-          for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = b[((size_t)y * W + x) * 4 + c];
+          for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = b[((size_t)y * W + x) * 4 + (bgra8 ? 2 - c : c)];
           f.write((const char*)row.data(), (std::streamsize)row.size());
         }
       } else {
@@ -223,7 +224,7 @@ int main(int argc, char** argv) {
         ring[k]->setUniforms(uniformStructure);
       }
       auto at = [&](int k) -> rthost::Renderer& { return k == 0 ? renderer : *ring[k]; };
-      for (int k = 0; k < inFlight; k++) { at(k).setParam("output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); if (blocksPerCu > 0) at(k).setParam("trace_blocks_per_cu", blocksPerCu); }
+      for (int k = 0; k < inFlight; k++) { at(k).setParam(bgra8 ? "output_bgra8" : "output_rgba8", rgba8 ? 1 : 0); at(k).setTiming(false); if (blocksPerCu > 0) at(k).setParam("trace_blocks_per_cu", blocksPerCu); }
       std::vector<char> pending(inFlight, 0);
       uint64_t rays = 0; int collected = 0;
       const void* px = nullptr;
@@ -262,10 +263,11 @@ int main(int argc, char** argv) {
         f << "P6\n" << W << " " << H << "\n255\n";
         std::vector<unsigned char> row((size_t)W * 3);
         for (int y = 0; y < H; y++) {
-          for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = b[((size_t)y * W + x) * 4 + c];
+          for (int x = 0; x < W; x++) for (int c = 0; c < 3; c++) row[(size_t)x * 3 + c] = b[((size_t)y * W + x) * 4 + (bgra8 ? 2 - c : c)];
           f.write((const char*)row.data(), (std::streamsize)row.size());
         }
-        printf("wrote %s.ppm (8-bit frame as stored by the device)\n", out.c_str());
+        if (bgra8) { std::ofstream raw(out + ".bgra", std::ios::binary); raw.write((const char*)b, (std::streamsize)((size_t)W * H * 4)); }
+        printf("wrote %s.ppm (8-bit frame as stored by the device%s)\n", out.c_str(), bgra8 ? "; raw B8G8R8A8 bytes in .bgra" : "");
         return 0;
       }
       const float* pf = static_cast<const float*>(px);

@@ -4,9 +4,11 @@
 // the traced image into the presented one (src/main.cpp:2683-2686).
 //
 // Per frame and slot: every device renders its interleaved 8-row bands on the slot's stream (rt_trace_shard), then ONE
-// gather brings the compact shards to the root over xGMI — ncclGather per device inside ncclGroupStart/End, each slot on its
-// own communicator so that frames in flight do not serialise on one — and the root de-interleaves (rt_assemble_shards) and
-// copies the frame to pinned host memory.  Nothing on the data path waits on the host between those steps.
+// gather brings the compact shards to the root over xGMI — ncclGather per device inside ncclGroupStart/End; the frame slots
+// share MAX_COMM_SETS communicator sets round-robin, so that frames in flight rarely queue behind one another on a
+// communicator without creating slots x devices of them — and the root de-interleaves (rt_assemble_shards) and copies the
+// frame to pinned host memory ("host_copy" 0: leaves it on the root device).  Nothing on the data path waits on the host
+// between those steps.
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
@@ -21,6 +23,7 @@
 namespace {
 
 constexpr int BAND_ROWS = 8;
+constexpr int MAX_COMM_SETS = 4;   // communicator sets (each: one communicator per device); slot j uses set j % n
 thread_local std::string g_create_error;
 
 struct Device {
@@ -38,7 +41,8 @@ struct rtm_ctx {
   int P = 1;
   int flags = 0;
   bool rgba8 = false;
-  std::vector<std::vector<ncclComm_t>> comm;   // [slot][device]
+  bool host_copy = true;                       // rtm_set_param "host_copy": copy every assembled frame to pinned host memory
+  std::vector<std::vector<ncclComm_t>> comm;   // [set][device], min(frames in flight, MAX_COMM_SETS) sets
   // root side, per slot
   std::vector<void*> gathered, frame;
   std::vector<void*> h_frame;
@@ -106,6 +110,40 @@ int ensure_buffers(rtm_ctx* c, int W, int H) {
   return RT_OK;
 }
 
+// steps 2 and 3 of a frame, enqueued behind the devices' bands: ONE gather of the compact shards to the root, the de-interleave
+// and (host_copy) the copy to pinned host memory
+int gather_and_assemble(rtm_ctx* c, int slot, int W, int H) {
+  const int n = (int)c->dev.size();
+  const size_t bpp = c->rgba8 ? 4 : 16, frame_bytes = (size_t)W * H * bpp;
+  hipStream_t root_stream = c->dev[0].streams[slot];
+  if (c->flags & RTM_LOOPBACK) {
+    for (int d = 0; d < n; d++) {
+      Device& D = c->dev[d];
+      HIPM(c, hipSetDevice(D.id));
+      if (d != 0) { HIPM(c, hipEventRecord(D.done[slot], D.streams[slot])); }
+    }
+    HIPM(c, hipSetDevice(c->dev[0].id));
+    for (int d = 0; d < n; d++) {
+      if (d != 0) HIPM(c, hipStreamWaitEvent(root_stream, c->dev[d].done[slot], 0));
+      HIPM(c, hipMemcpyAsync((char*)c->gathered[slot] + (size_t)d * c->stride, c->dev[d].shard[slot], c->stride, hipMemcpyDeviceToDevice, root_stream));
+    }
+  } else {
+    std::vector<ncclComm_t>& set = c->comm[(size_t)slot % c->comm.size()];
+    NCCLM(c, ncclGroupStart());
+    for (int d = 0; d < n; d++) {
+      Device& D = c->dev[d];
+      HIPM(c, hipSetDevice(D.id));
+      NCCLM(c, ncclGather(D.shard[slot], d == 0 ? c->gathered[slot] : nullptr, c->stride, ncclUint8, 0, set[d], D.streams[slot]));
+    }
+    NCCLM(c, ncclGroupEnd());
+  }
+  // the root de-interleaves and hands the frame to the host
+  HIPM(c, hipSetDevice(c->dev[0].id));
+  RTM(c, 0, slot, rt_assemble_shards(c->dev[0].slots[slot], c->gathered[slot], n, c->stride, W, H, BAND_ROWS, c->frame[slot], c->frame_bytes, root_stream));
+  if (c->host_copy) HIPM(c, hipMemcpyAsync(c->h_frame[slot], c->frame[slot], frame_bytes, hipMemcpyDeviceToHost, root_stream));
+  return RT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -146,9 +184,11 @@ int rtm_create(rtm_ctx** out, int n_devices, const int* device_ids, int frames_i
   c->gathered.assign(c->P, nullptr); c->frame.assign(c->P, nullptr); c->h_frame.assign(c->P, nullptr);
   c->pending_w.assign(c->P, 0); c->pending_h.assign(c->P, 0);
   if (!(flags & RTM_LOOPBACK)) {
-    // one communicator set per frame slot: collectives of different frames in flight never queue behind one another
-    c->comm.assign(c->P, std::vector<ncclComm_t>(n_devices, nullptr));
-    for (int j = 0; j < c->P; j++) {
+    // a few communicator sets shared by the frame slots: collectives of frames in flight rarely queue behind one another, and the
+    // number of communicators does not grow with slots x devices (16 x 8 = 128 of them took seconds to create and pinned buffers each)
+    const int n_sets = std::min(c->P, MAX_COMM_SETS);
+    c->comm.assign(n_sets, std::vector<ncclComm_t>(n_devices, nullptr));
+    for (int j = 0; j < n_sets; j++) {
       ncclResult_t r = ncclCommInitAll(c->comm[j].data(), n_devices, device_ids);
       if (r != ncclSuccess) { c->error = std::string("ncclCommInitAll: ") + ncclGetErrorString(r); return bail(RT_ERR_DEVICE); }
     }
@@ -200,11 +240,29 @@ int rtm_set_skybox(rtm_ctx* c, const uint8_t* const faces[6], int w, int h) {
 }
 int rtm_set_param(rtm_ctx* c, const char* name, int value) {
   if (!c || !name) return RT_ERR_INVALID_ARGUMENT;
+  if (std::string(name) == "host_copy") { c->host_copy = value != 0; return RT_OK; }   // this library's own knob (not an rt_set_param)
   for (size_t d = 0; d < c->dev.size(); d++)
     for (int j = 0; j < c->P; j++) RTM(c, d, j, rt_set_param(c->dev[d].slots[j], name, value));
-  if (std::string(name) == "output_rgba8") { c->rgba8 = value != 0; c->stride = 0; c->frame_bytes = 0; }
+  if (std::string(name) == "output_rgba8" || std::string(name) == "output_bgra8") { c->rgba8 = value != 0; c->stride = 0; c->frame_bytes = 0; }
   return RT_OK;
 }
+int rtm_set_materials(rtm_ctx* c, const rt_material* table, int n_materials, const uint32_t* prim_material, size_t n_prims) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  for (size_t d = 0; d < c->dev.size(); d++) RTM(c, d, 0, rt_set_materials(c->dev[d].slots[0], table, n_materials, prim_material, n_prims));
+  return RT_OK;
+}
+int rtm_set_instance_types(rtm_ctx* c, int slot, const uint32_t* types, int n) {
+  if (!c || slot < 0 || slot >= c->P) return RT_ERR_INVALID_ARGUMENT;
+  for (size_t d = 0; d < c->dev.size(); d++) RTM(c, d, slot, rt_set_instance_types(c->dev[d].slots[slot], types, n));
+  return RT_OK;
+}
+int rtm_set_timing(rtm_ctx* c, int enabled) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  for (int j = 0; j < c->P; j++) RTM(c, 0, j, rt_set_timing(c->dev[0].slots[j], enabled));
+  return RT_OK;
+}
+const void* rtm_frame_device(const rtm_ctx* c, int slot) { return (c && slot >= 0 && slot < c->P) ? c->frame[slot] : nullptr; }
+
 int rtm_set_instances(rtm_ctx* c, int slot, const rt_instance* inst, int n, int update) {
   if (!c || slot < 0 || slot >= c->P) return RT_ERR_INVALID_ARGUMENT;
   for (size_t d = 0; d < c->dev.size(); d++) RTM(c, d, slot, rt_set_instances(c->dev[d].slots[slot], inst, n, update));
@@ -221,38 +279,12 @@ int rtm_trace_async(rtm_ctx* c, int slot, int W, int H) {
   if (c->pending_w[slot]) return fail(c, RT_ERR_NOT_READY, "rtm_trace_async: the previous frame of this slot has not been collected (rtm_trace_wait)");
   int r = ensure_buffers(c, W, H); if (r) return r;
   const int n = (int)c->dev.size();
-  const size_t bpp = c->rgba8 ? 4 : 16, frame_bytes = (size_t)W * H * bpp;
   // 1. every device renders its bands on the slot's stream
   for (int d = 0; d < n; d++) {
     Device& D = c->dev[d];
     RTM(c, d, slot, rt_trace_shard(D.slots[slot], W, H, BAND_ROWS, d, n, D.shard[slot], c->stride, D.streams[slot]));
   }
-  hipStream_t root_stream = c->dev[0].streams[slot];
-  // 2. ONE gather of the compact shards to the root
-  if (c->flags & RTM_LOOPBACK) {
-    for (int d = 0; d < n; d++) {
-      Device& D = c->dev[d];
-      HIPM(c, hipSetDevice(D.id));
-      if (d != 0) { HIPM(c, hipEventRecord(D.done[slot], D.streams[slot])); }
-    }
-    HIPM(c, hipSetDevice(c->dev[0].id));
-    for (int d = 0; d < n; d++) {
-      if (d != 0) HIPM(c, hipStreamWaitEvent(root_stream, c->dev[d].done[slot], 0));
-      HIPM(c, hipMemcpyAsync((char*)c->gathered[slot] + (size_t)d * c->stride, c->dev[d].shard[slot], c->stride, hipMemcpyDeviceToDevice, root_stream));
-    }
-  } else {
-    NCCLM(c, ncclGroupStart());
-    for (int d = 0; d < n; d++) {
-      Device& D = c->dev[d];
-      HIPM(c, hipSetDevice(D.id));
-      NCCLM(c, ncclGather(D.shard[slot], d == 0 ? c->gathered[slot] : nullptr, c->stride, ncclUint8, 0, c->comm[slot][d], D.streams[slot]));
-    }
-    NCCLM(c, ncclGroupEnd());
-  }
-  // 3. the root de-interleaves and hands the frame to the host
-  HIPM(c, hipSetDevice(c->dev[0].id));
-  RTM(c, 0, slot, rt_assemble_shards(c->dev[0].slots[slot], c->gathered[slot], n, c->stride, W, H, BAND_ROWS, c->frame[slot], c->frame_bytes, root_stream));
-  HIPM(c, hipMemcpyAsync(c->h_frame[slot], c->frame[slot], frame_bytes, hipMemcpyDeviceToHost, root_stream));
+  r = gather_and_assemble(c, slot, W, H); if (r) return r;
   c->pending_w[slot] = W; c->pending_h[slot] = H;
   return RT_OK;
 }
@@ -260,18 +292,28 @@ int rtm_trace_async(rtm_ctx* c, int slot, int W, int H) {
 int rtm_trace_wait(rtm_ctx* c, int slot, const void** pixels, rt_stats* stats) {
   if (!c || slot < 0 || slot >= c->P) return RT_ERR_INVALID_ARGUMENT;
   if (!c->pending_w[slot]) return fail(c, RT_ERR_NOT_READY, "rtm_trace_wait without rtm_trace_async");
+  const int W = c->pending_w[slot], H = c->pending_h[slot];
   c->pending_w[slot] = c->pending_h[slot] = 0;
   rt_stats sum{};
+  bool again = false;
   for (size_t d = 0; d < c->dev.size(); d++) {
     rt_stats st{};
     RTM(c, d, slot, rt_get_stats(c->dev[d].slots[slot], &st));   // waits for the device's part of the frame
-    sum.rays_primary += st.rays_primary; sum.rays_secondary += st.rays_secondary; sum.rays_shadow += st.rays_shadow;
-    sum.closest_rays += st.closest_rays; sum.tail_faults += st.tail_faults;
-    sum.bvh_node_bytes = st.bvh_node_bytes; sum.bvh_tri_bytes = st.bvh_tri_bytes;
+    if (d == 0) sum = st;                                         // kernel times, visit counters: the root device's
+    else { sum.rays_primary += st.rays_primary; sum.rays_secondary += st.rays_secondary; sum.rays_shadow += st.rays_shadow; sum.closest_rays += st.closest_rays;
+           sum.tail_faults += st.tail_faults; sum.frames_rerendered += st.frames_rerendered; }
+    again = again || st.frames_rerendered != 0;
+  }
+  if (again) {
+    // a device rendered its bands a second time (k_tail fault, rt_api.h rt_trace_shard): the gather enqueued behind the first
+    // attempt took the incomplete shard — gather, de-interleave and copy this slot's frame again
+    int r = gather_and_assemble(c, slot, W, H); if (r) return r;
+    if (!(c->flags & RTM_LOOPBACK))
+      for (auto& D : c->dev) { HIPM(c, hipSetDevice(D.id)); HIPM(c, hipStreamSynchronize(D.streams[slot])); }
   }
   HIPM(c, hipSetDevice(c->dev[0].id));
   HIPM(c, hipStreamSynchronize(c->dev[0].streams[slot]));        // gather, de-interleave, copy
-  if (pixels) *pixels = c->h_frame[slot];
+  if (pixels) *pixels = c->host_copy ? c->h_frame[slot] : nullptr;
   if (stats) *stats = sum;
   return RT_OK;
 }

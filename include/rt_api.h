@@ -112,7 +112,8 @@ typedef struct rt_stats {
   uint32_t bvh_tri_bytes;
   uint32_t tail_faults;      /* frames of this context that were rendered again with per-bounce launches because a k_tail grid
                                 barrier gave up (its workgroups were not co-resident); the context stays off k_tail afterwards */
-  uint32_t reserved0;
+  uint32_t frames_rerendered; /* 1 when the frame these statistics belong to had to be rendered a second time (k_tail fault): a copy of
+                                the frame taken BEFORE this call returned (a gather or memcpy enqueued behind rt_trace_shard) is stale */
 } rt_stats;
 
 /* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */
@@ -175,7 +176,13 @@ int rt_set_skybox(rt_ctx* ctx, const uint8_t* const faces_rgba8[6], int w, int h
  * whole frame (row 0 = top, RGBA32F, the shader's declared rgba32f format src/shader.rgen:48) to host. */
 int rt_trace(rt_ctx* ctx, int width, int height, float* out_rgba32f_host, rt_stats* stats);
 
-/* Sharded, asynchronous form used for multi-GPU tiling (one process per GPU).  Renders the row bands
+/* Sharded, asynchronous form used for multi-GPU tiling (one process per GPU).  d_out must stay valid, and is only guaranteed
+ * complete, after the rt_synchronize / rt_get_stats that follows the call: should a grid barrier of the bounce kernel give
+ * up (rt_stats.tail_faults), that call renders the frame again into d_out — from the uniforms and instance records the
+ * frame was submitted with — and reports rt_stats.frames_rerendered = 1; work the caller enqueued behind the frame on its
+ * own stream (a gather, a copy) has then consumed the incomplete frame and must be repeated.  Frames enqueued back to back
+ * on one context without collecting each: a fault in an earlier one is still reported and switches the context to
+ * per-bounce launches, but only the most recent frame is rendered again.  Renders the row bands
  * {b : b % n_shards == shard} of band_rows rows each and writes them COMPACTLY (band after band, each
  * band_rows x width x 4 floats; the last band of the frame may be short) into d_out, a DEVICE pointer
  * owned by the caller (e.g. a torch tensor), enqueued on hip_stream (NULL = the context's stream).

@@ -40,7 +40,15 @@ int rtm_upload_geometry(rtm_ctx* ctx, const float* verts6, size_t n_floats, cons
                         const rt_mesh_range* ranges, int n_meshes);
 int rtm_build_blas(rtm_ctx* ctx, int mesh);
 int rtm_set_skybox(rtm_ctx* ctx, const uint8_t* const faces_rgba8[6], int w, int h);
+/* rt_set_param on every slot of every device; plus this library's own "host_copy" (default 1; 0: rtm_trace_wait hands out no
+ * host pixels, the assembled frame stays on the root device: rtm_frame_device). */
 int rtm_set_param(rtm_ctx* ctx, const char* name, int value);
+/* SURVEY.md §8(f) row n4 on several GPUs: the MTL material table (scene state, replicated) and the per-instance types of one
+ * slot — rt_set_materials / rt_set_instance_types on every device (src/shader.rgen:51-55, :96). */
+int rtm_set_materials(rtm_ctx* ctx, const rt_material* table, int n_materials, const uint32_t* prim_material, size_t n_prims);
+int rtm_set_instance_types(rtm_ctx* ctx, int slot, const uint32_t* types, int n);
+/* rt_set_timing on the ROOT device's slots: rtm_trace_wait's stats carry that device's kernel times. */
+int rtm_set_timing(rtm_ctx* ctx, int enabled);
 
 /* Per-frame state of one slot, pushed to every device (src/main.cpp:2848-2861, 2901-2903). */
 int rtm_set_instances(rtm_ctx* ctx, int slot, const rt_instance* instances, int n, int update);
@@ -50,9 +58,14 @@ int rtm_set_uniforms(rtm_ctx* ctx, int slot, const rt_uniforms* u);
  * de-interleave and the copy to a pinned host buffer; returns at once. */
 int rtm_trace_async(rtm_ctx* ctx, int slot, int width, int height);
 /* vkWaitForFences for that frame: pixels = width*height RGBA32F (or RGBA8 after rtm_set_param "output_rgba8" 1), valid
- * until the next rtm_trace_async on the slot; stats = ray counts summed over the devices. */
+ * until the next rtm_trace_async on the slot (NULL with "host_copy" 0); stats = ray counts summed over the devices, kernel
+ * times and visit counters of the root device.  If a device had to render its bands a second time (rt_stats.frames_rerendered,
+ * a k_tail fault) the gather, de-interleave and copy of the slot are repeated here before the call returns. */
 int rtm_trace_wait(rtm_ctx* ctx, int slot, const void** pixels, rt_stats* stats);
 
+/* Device pointer (root GPU) of the slot's assembled width*height frame, valid after rtm_trace_wait until the next
+ * rtm_trace_async on the slot (and across buffer growth only until then). */
+const void* rtm_frame_device(const rtm_ctx* ctx, int slot);
 int rtm_device_count(const rtm_ctx* ctx);
 const char* rtm_last_error(const rtm_ctx* ctx);
 

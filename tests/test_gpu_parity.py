@@ -1330,3 +1330,195 @@ def test_shadow_entry_points_are_result_identical(ctx):
     wl1 = workloads.make("cfg1", RES)
     wl1.apply(ctx)
     both(256, 256)
+
+
+def test_tail_fault_rerenders_the_submitted_frame_on_the_shard_and_multi_gpu_paths(ctx):
+    """the k_tail fault fallback on the rt_trace_shard path.  (1) The re-render uses the uniforms and instance
+    records the frame was SUBMITTED with, even if rt_set_uniforms / one rt_set_instances ran before the frame was collected;
+    two instance updates before collecting make the frame unrecoverable and that is reported, not papered over.  (2) A fault in
+    an earlier frame of a stream of uncollected frames is still counted (sticky device-side total) and switches the slot off
+    k_tail.  (3) librt_multi.so (loopback, 3 logical devices): rtm_trace_wait learns of the re-render (frames_rerendered) and
+    gathers, de-interleaves and copies the slot again, so the frame it hands out is complete."""
+    import torch
+    from vulkan_raytracing_amd import multi
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 2, 1, 12, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.5)
+    W, H = 160, 96
+    good, st0 = ctx.trace(W, H)
+    u_other = sp.uniforms.copy()
+    u_other[0]["position"][:3] = (3.0, 2.0, 14.0)
+    inst_other = sp.instances.copy()
+    inst_other[1]["transform"][3] += 1.5
+    stream = torch.cuda.Stream()
+    buf = torch.zeros((H, W, 4), dtype=torch.float32, device="cuda:0")
+    c2 = RtContext(0)
+    try:
+        scenes.ScenePair(sp.geom_paths, sp.instances, sp.uniforms, sky=sp.sky, ctx=c2)
+        c2.set_param("tail_kernel", 2)
+        # (1) uniforms and ONE instance update between submit and collect
+        c2.set_param("debug_force_tail_fault", 1)
+        c2.trace_shard(W, H, H, 0, 1, buf.data_ptr(), buf.numel() * 4, stream.cuda_stream)
+        c2.set_uniforms(u_other)
+        c2.set_instances(inst_other, update=True)
+        st = c2.stats()
+        assert st.tail_faults == 1 and st.frames_rerendered == 1
+        assert np.array_equal(buf.cpu().numpy(), good), "the re-rendered frame is not the submitted one"
+        c2.trace_shard(W, H, H, 0, 1, buf.data_ptr(), buf.numel() * 4, stream.cuda_stream)     # the new state renders a different frame, no re-render
+        st = c2.stats()
+        assert st.frames_rerendered == 0 and not np.array_equal(buf.cpu().numpy(), good)
+        # two updates before collecting: the frame's records are gone, and the call says so
+        c2.set_uniforms(sp.uniforms); c2.set_instances(sp.instances, update=True)
+        c2.set_param("debug_force_tail_fault", 2)      # 2: also re-arms k_tail on this context
+        c2.trace_shard(W, H, H, 0, 1, buf.data_ptr(), buf.numel() * 4, stream.cuda_stream)
+        c2.set_instances(inst_other, update=True); c2.set_instances(sp.instances, update=True)
+        with pytest.raises(RtError) as e:
+            c2.stats()
+        assert "cannot be rendered again" in str(e.value)
+        c2.trace_shard(W, H, H, 0, 1, buf.data_ptr(), buf.numel() * 4, stream.cuda_stream)
+        c2.synchronize()
+        assert np.array_equal(buf.cpu().numpy(), good)
+    finally:
+        c2.close()
+    # (3) three logical devices, two slots: a forced fault on every slot of every device
+    m = multi.RtMulti([0, 0, 0], 2, loopback=True)
+    try:
+        g = sp.geom
+        m.upload_geometry(g.verts, g.idx, g.ranges)
+        m.set_instances(sp.instances); m.set_uniforms(sp.uniforms); m.set_skybox(sp.sky)
+        m.set_param("tail_kernel", 2)
+        m.trace_async(0, W, H)
+        ok, s_ok = m.trace_wait(0)
+        assert np.array_equal(ok, good) and s_ok.frames_rerendered == 0
+        m.set_param("debug_force_tail_fault", 1)
+        m.trace_async(1, W, H); m.trace_async(0, W, H)
+        for slot in (1, 0):
+            img, s1 = m.trace_wait(slot)
+            assert s1.frames_rerendered == 3 and s1.tail_faults == 3, (s1.frames_rerendered, s1.tail_faults)
+            assert np.array_equal(img, good), "slot %d: the gathered frame is stale" % slot
+            assert (s1.rays_primary, s1.rays_secondary, s1.rays_shadow) == (st0.rays_primary, st0.rays_secondary, st0.rays_shadow)
+    finally:
+        m.close()
+
+
+def test_bgra8_surface_byte_order_and_materials_on_the_multi_gpu_host(ctx, tmp_path):
+    """Row n2: the reference's storage image has the surface format, normally B8G8R8A8 (src/main.cpp:1204, 1899):
+    rt_set_param "output_bgra8" stores the 8-bit frame in that byte order = the RGBA8 frame with R and B swapped, on the
+    single-GPU path, through rt_assemble_shards (3 logical devices) and in rt_headless --bgra8.  Row n4 on the multi-GPU
+    host: rtm_set_materials / rtm_set_instance_types give the frame the single-GPU path renders with the same table."""
+    import subprocess
+    from vulkan_raytracing_amd import multi
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.3)
+    W, H = 200, 120
+    try:
+        ctx.set_param("output_rgba8", 1)
+        rgba, _ = ctx.trace(W, H)
+        ctx.set_param("output_bgra8", 1)
+        bgra, _ = ctx.trace(W, H)
+    finally:
+        ctx.set_param("output_rgba8", 0)
+    assert rgba.dtype == np.uint8 and rgba.std() > 5 and np.array_equal(bgra[..., [2, 1, 0, 3]], rgba)
+    g = sp.geom
+    n_prims = len(g.idx) // 3
+    from vulkan_raytracing_amd.api import MATERIAL_DTYPE, MATERIAL_TYPE_OF_INSTANCE
+    table = np.zeros(3, MATERIAL_DTYPE)
+    table[0] = ((0.1, 0.3, 0.1), 100.0, (0.2, 1.0, 0.2), 1.52, (0.8, 0.8, 0.8), MATERIAL_TYPE_OF_INSTANCE)
+    table[1] = ((0.3, 0.1, 0.1), 20.0, (0.9, 0.3, 0.2), 1.33, (0.5, 0.5, 0.5), 0)
+    table[2] = ((0.1, 0.1, 0.3), 60.0, (0.2, 0.3, 0.9), 1.45, (0.9, 0.9, 0.9), 2)
+    pm = (np.arange(n_prims) % 3).astype(np.uint32)
+    ctx.set_materials(table, pm)
+    ctx.set_instance_types([2, 0])
+    try:
+        ref_mat, st_ref = ctx.trace(W, H)
+        ctx.set_param("output_bgra8", 1)
+        ref_mat8, _ = ctx.trace(W, H)
+    finally:
+        ctx.set_param("output_rgba8", 0)
+        ctx.set_materials(None)
+        ctx.set_instance_types(None)
+    m = multi.RtMulti([0, 0, 0], 2, loopback=True)
+    try:
+        m.upload_geometry(g.verts, g.idx, g.ranges)
+        m.set_instances(sp.instances); m.set_uniforms(sp.uniforms); m.set_skybox(sp.sky)
+        m.set_materials(table, pm)
+        m.set_instance_types([2, 0])
+        m.trace_async(1, W, H)
+        img, st = m.trace_wait(1)
+        assert np.array_equal(img, ref_mat)
+        assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (st_ref.rays_primary, st_ref.rays_secondary, st_ref.rays_shadow)
+        m.set_param("output_bgra8", 1)
+        m.trace_async(0, W, H)
+        img8, _ = m.trace_wait(0)
+        assert img8.dtype == np.uint8 and np.array_equal(img8, ref_mat8)
+    finally:
+        m.close()
+    exe = os.path.join(scenes.ROOT, "rt_headless")
+    common = ["--width", "160", "--height", "96", "--frames", "2", "--dt", "0.5", "--bounce", "2", "--spp", "2", "--frames-in-flight", "2",
+              "--center", os.path.join(RES, "teapot.obj"), "--orbiting", os.path.join(RES, "cube.obj"), "--skybox", os.path.join(RES, "skybox_texture_test")]
+    raw = {}
+    for name, extra in (("a", ["--rgba8"]), ("b", ["--bgra8"])):
+        out = str(tmp_path / name)
+        r = subprocess.run([exe] + common + extra + ["--out", out], cwd=scenes.ROOT, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-500:] + r.stderr[-1000:]
+        raw[name] = open(out + ".ppm", "rb").read()
+    assert raw["a"] == raw["b"]                                    # the PPM view is swizzled back
+    b = np.frombuffer(open(str(tmp_path / "b") + ".bgra", "rb").read(), np.uint8).reshape(96, 160, 4)
+    ppm = np.frombuffer(raw["b"][raw["b"].index(b"255\n") + 4:], np.uint8).reshape(96, 160, 3)
+    assert np.array_equal(b[..., [2, 1, 0]], ppm)
+
+
+def test_bench_one_process_multi_gpu_host_reassembles_the_same_frame(tmp_path):
+    """bench.py --host multi: ONE process drives N (here 2 logical, --loopback) devices through librt_multi.so; its frame equals
+    the single-GPU bench frame bit for bit and the line carries n_gpus."""
+    import json
+    import subprocess
+    import sys
+    a, b = str(tmp_path / "one.pfm"), str(tmp_path / "multi.pfm")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extras", "--save-image", a],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--host", "multi", "--loopback", "--steps", "4", "--warmup", "2",
+                        "--no-extras", "--save-image", b], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert line["n_gpus"] == 2 and line["config"]["host"] == "multi" and line["value"] > 0
+    assert open(a, "rb").read() == open(b, "rb").read()
+
+
+def test_far_origins_up_to_the_pipelines_tmax_and_beyond(ctx):
+    """the conservative box test from FAR origins.  The pipeline's tmax is 10000 (src/shader.rgen:86-87) and
+    the camera flies freely, so hits from thousands of units away are reachable; there the rounding of (plane - origin) exceeds
+    the margin of the stored planes and used to lose a record in 40 000 from 20 000 units.  Rays whose origin is that far now
+    take the generic visit with a per-axis widened slab test (kernels.hip quant_far): hit records must equal the oracle's brute
+    force bit for bit from 20 to 200 000 units, closest hit and any hit, through instance transforms; and a frame rendered from
+    5000 units away equals the oracle's."""
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 1, 1, ctx=ctx, time_param=0.3)
+    rng = np.random.default_rng(5)
+    for dist in (20.0, 700.0, 2000.0, 5000.0, 10000.0, 20000.0, 60000.0, 200000.0):
+        n = 30000
+        o = rng.normal(size=(n, 3)); o /= np.linalg.norm(o, axis=1, keepdims=True); o *= dist
+        tgt = rng.uniform(-2.5, 2.5, (n, 3)); tgt[:, 1] = rng.uniform(0, 1.6, n)
+        half = rng.random(n) < 0.5
+        tgt[half] = rng.uniform(-1.2, 1.2, (int(half.sum()), 3))
+        # a third of the rays nearly parallel to a coordinate axis: the case no relative slack in t covers
+        ax = rng.integers(0, 3, n)
+        par = rng.random(n) < 0.33
+        o[par] = tgt[par]
+        o[par, ax[par]] += dist * rng.choice([-1.0, 1.0], int(par.sum()))
+        o[par] += rng.normal(scale=1e-3, size=(int(par.sum()), 3))
+        d = tgt - o; d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.zeros((n, 8), np.float32); rays[:, 0:3] = o; rays[:, 3] = 0.001; rays[:, 4:7] = d; rays[:, 7] = 1e9
+        g, _ = ctx.intersect(rays)
+        b = sp.orc.intersect(rays, use_bvh=False)
+        same = (g["prim"] == b["prim"]) & (g["inst"] == b["inst"]) & (g["t"].view(np.uint32) == b["t"].view(np.uint32))
+        assert (b["inst"] >= 0).mean() > 0.3
+        assert same.all(), "from %g units: %d of %d hit records differ from brute force" % (dist, int((~same).sum()), n)
+        ga, _ = ctx.intersect(rays, any_hit=True)
+        assert np.array_equal(ga["inst"] >= 0, b["inst"] >= 0)
+    u = sp.uniforms.copy()
+    u[0]["position"][:3] = (0.0, 0.0, 5000.0)
+    u[0]["forward"][:3] = (0.0, 0.0, -2000.0)       # a long lens (the shader takes the vectors as they come): the scene fills part of the frame
+    sp.set_uniforms(u)
+    img, st = ctx.trace(200, 120)
+    ref, rc = sp.orc.render(200, 120)
+    check_image(img, ref)
+    assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2])) and st.rays_shadow > 100

@@ -26,7 +26,7 @@ class RtStats(C.Structure):
                 ("ms_frame", C.c_float), ("ms_raygen", C.c_float), ("ms_trace_closest", C.c_float), ("ms_trace_shadow", C.c_float),
                 ("ms_shade", C.c_float), ("ms_resolve", C.c_float),
                 ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32), ("timed_frames", C.c_uint32), ("ms_tail", C.c_float),
-                ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32), ("tail_faults", C.c_uint32), ("reserved0", C.c_uint32)]
+                ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32), ("tail_faults", C.c_uint32), ("frames_rerendered", C.c_uint32)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k == "diag" else getattr(self, k)) for k, _ in self._fields_}
@@ -221,7 +221,7 @@ class RtContext:
 
     def set_param(self, name, value):
         self._chk(self.L.rt_set_param(self.h, name.encode(), int(value)), "rt_set_param")
-        if name == "output_rgba8":
+        if name in ("output_rgba8", "output_bgra8"):
             self._rgba8 = bool(value)   # frames come back as uint8 (H, W, 4)
 
     def intersect(self, rays8, any_hit=False, counting=False):

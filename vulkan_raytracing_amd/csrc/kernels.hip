@@ -175,6 +175,27 @@ __device__ __forceinline__ bool slab_q(uint32_t wx, uint32_t wy, uint32_t wz, F3
   const float tf = fminf(fminf(x1, y1), fminf(z1, tlim));
   return tn <= tf * 1.00002f;
 }
+// The one ABSOLUTE error of the plane distances: qb = (q_lo - o) / d loses what the subtraction q_lo - o rounds away, up to half an
+// ulp of |q_lo - o| IN SPACE — nothing while the origin is near the tree, but from thousands of units away (the pipeline's tmax
+// is 10000, src/shader.rgen:86-87, and the camera flies freely) it exceeds the two quanta of margin in the stored planes, and on
+// an axis the ray is nearly perpendicular to no relative slack in t covers it (tools/far_probe.py: 1 record in 40 000 wrong from
+// 20 000 units).  A ray is FAR when that rounding can reach a quarter of a quantum on some axis; far rays take the generic visit
+// (interior_step), whose slab test moves every near plane down and every far plane up by 2^-22 |qb| on its own axis.  The
+// headline's rays are never far (|q_lo - o| / q_scale ~ 2.5e5 quanta against the threshold of 2.1e6).
+__device__ __forceinline__ bool quant_far(F3 qs, F3 qb) {
+  const float K = 2097152.0f;   // 0.25 quantum / 2^-23
+  return __builtin_fabsf(qb.x) > K * __builtin_fabsf(qs.x) || __builtin_fabsf(qb.y) > K * __builtin_fabsf(qs.y) || __builtin_fabsf(qb.z) > K * __builtin_fabsf(qs.z);
+}
+__device__ __forceinline__ bool slab_q_far(uint32_t wx, uint32_t wy, uint32_t wz, F3 qs, F3 qb, uint3 rot, float tmin, float tlim, float& tn) {
+  const float ex = 2.4e-7f * __builtin_fabsf(qb.x), ey = 2.4e-7f * __builtin_fabsf(qb.y), ez = 2.4e-7f * __builtin_fabsf(qb.z);
+  wx = __builtin_amdgcn_alignbit(wx, wx, rot.x); wy = __builtin_amdgcn_alignbit(wy, wy, rot.y); wz = __builtin_amdgcn_alignbit(wz, wz, rot.z);
+  const float x0 = __builtin_fmaf((float)(wx & 0xFFFFu), qs.x, qb.x) - ex, x1 = __builtin_fmaf((float)(wx >> 16), qs.x, qb.x) + ex;
+  const float y0 = __builtin_fmaf((float)(wy & 0xFFFFu), qs.y, qb.y) - ey, y1 = __builtin_fmaf((float)(wy >> 16), qs.y, qb.y) + ey;
+  const float z0 = __builtin_fmaf((float)(wz & 0xFFFFu), qs.z, qb.z) - ez, z1 = __builtin_fmaf((float)(wz >> 16), qs.z, qb.z) + ez;
+  tn = fmaxf(fmaxf(x0, y0), fmaxf(z0, tmin));
+  const float tf = fminf(fminf(x1, y1), fminf(z1, tlim));
+  return tn <= tf * 1.00002f;
+}
 // (qs, qb, rot) of a ray in the space of a tree with dequantisation (q_lo, q_scale)
 __device__ __forceinline__ void quant_space(F3 o, F3 d, const float* q_lo, const float* q_scale, F3& qs, F3& qb, uint3& rot) {
   const F3 id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
@@ -670,12 +691,13 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
       F3 qs, qb; uint3 rot;
       quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
+      const bool far = quant_far(qs, qb);   // a camera thousands of units from the scene: widened slab tests (see quant_far)
       // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
       const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
       const uint4 Q0 = rp[0], Q1 = rp[1];
       float tn;
-      const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
-      const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) && Q1.w != Q1.z;
+      const bool h0 = far ? slab_q_far(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn) : slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
+      const bool h1 = (far ? slab_q_far(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) : slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn)) && Q1.w != Q1.z;
       const int c0 = (int)Q1.z, c1 = (int)Q1.w;
       survive = (h0 && c0 < 0) || (h1 && c1 < 0);
 #pragma unroll
@@ -684,7 +706,8 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
         if ((k ? h1 : h0) && ch >= 0 && !survive) {
           const uint4* np = reinterpret_cast<const uint4*>(sc.blas_nodes + ch);
           const uint4 N0 = np[0], N1 = np[1];
-          survive = slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn);
+          survive = far ? (slab_q_far(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q_far(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn))
+                        : (slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn));
         }
       }
     }
@@ -880,6 +903,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   float tmin_ray = 0.f, tmax = 0.f;   // tmin is a per-ray value only in the raw mode; the pipeline uses one constant
   F3 wo = mk3(0, 0, 0), wd = mk3(0, 0, 1), co = wo, cd = wd, qs = mk3(1, 1, 1), qb = mk3(0, 0, 0);
   uint3 rot = make_uint3(0u, 0u, 0u);
+  bool far = false;   // quant_far() of the current space: this lane's visits take the generic path with the widened slab test
   float best_t = 0.f, best_u = 0.f, best_v = 0.f;
   int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
   // BLAS nodes, then the TLAS nodes (WIDE: the 64-byte 4-ary records with the same numbering)
@@ -917,7 +941,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
       co = xform_point(m, wo); cd = xform_vec(m, wd);
       const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
-      quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
+      quant_space(co, cd, qlo3, qsc3, qs, qb, rot); far = quant_far(qs, qb);
     }
   };
 
@@ -956,7 +980,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             }
             const uint32_t hdr = (uint32_t)r0.x;
             if (ent == ENTRY_FROM_ROOT) {
-              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb);
               sp = 1; cur = a.sc.tlas_root;
             } else if (hdr == ENTRY_EMPTY) {
               sp = 1; cur = REF_DONE;   // nothing a ray of this tile can hit: the ray is finished (a miss)
@@ -976,10 +1000,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
               sp = 1 + (int)nw;
               cur = cur_new;
               if (ia != ENTRY_NO_INST) { int root; uint32_t imask; to_instance((int)ia, root, imask); cur_inst = (int)ia; }   // (k_entry never names an invisible instance)
-              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb);
             }
           } else {
-            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb);
             sp = 1;
             cur = a.sc.tlas_root;   // TLAS root (always interior)
           }
@@ -1002,10 +1026,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           const uint4 X = np[0], Y = np[1], Z = np[2], R = np[3];
           if (COUNT) cnt_nodes++;
           float t0, t1, t2, t3;
-          const bool h0 = slab_q(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
-          const bool h1 = slab_q(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
-          const bool h2 = slab_q(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2);
-          const bool h3 = slab_q(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3);
+          const bool h0 = far ? slab_q_far(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0) : slab_q(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+          const bool h1 = far ? slab_q_far(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1) : slab_q(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+          const bool h2 = far ? slab_q_far(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2) : slab_q(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2);
+          const bool h3 = far ? slab_q_far(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3) : slab_q(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3);
           // entry distance with the entry number in its two low mantissa bits; a miss sorts last
           uint32_t k0 = h0 ? (__float_as_uint(t0) & ~3u) : 0xFFFFFFFFu;
           uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFFu;
@@ -1043,8 +1067,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
-        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
-        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+        const bool h0 = far ? slab_q_far(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0) : slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+        const bool h1 = far ? slab_q_far(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1) : slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
         if (h0 && h1) {
           const bool swap = t1 < t0;
           push(swap ? ch.x : ch.y);
@@ -1106,7 +1130,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
 #endif
       // fast visits need every stack they touch inside the LDS rows: sp - 1 >= 0 always holds for a live ray, and
       // UNROLL pushes must fit below row STACK2_LDS
-      const bool deep = cur >= 0 && sp + UNROLL > STACK2_LDS;
+      const bool deep = cur >= 0 && (sp + UNROLL > STACK2_LDS || far);   // far rays: the generic visit has the widened slab test
 #ifdef RT_EXP_DEEP_DIAG   // experiment: diag = (interior loop votes, votes that took the generic deep-stack path, wave cycles)
       if (COUNT && lane == 0) { diag_iters++; diag_busy += __ballot(deep) != 0 ? 1u : 0u; }
 #endif
@@ -1136,10 +1160,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         if (COUNT) cnt_tris++;
         float tt, uu, vv;
         if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), (ANY ? best_t : tmax), tt, uu, vv)) {
-          const int prim = (int)__float_as_uint(T2.y);
-          const bool better = (best_inst < 0) || (tt < best_t) ||
-                              (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
-          if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
+          if (ANY && MODE == MODE_SHADOW) best_inst = cur_inst;   // the shadow pipeline only asks WHETHER something was hit: no record to keep
+          else {
+            const int prim = (int)__float_as_uint(T2.y);
+            const bool better = (best_inst < 0) || (tt < best_t) ||
+                                (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
+            if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
+          }
         }
       }
       if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
@@ -1152,7 +1179,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       // an interior TLAS node (a TLAS leaf sets up its own space, and the bottom sentinel ends the ray)
       cur_inst = -1;
       pop();
-      if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+      if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb); }
     }
     PH_END(2)
     PH_BEGIN(3)
@@ -1163,7 +1190,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       to_instance(ii, root, imask);
       if ((imask & 0xFFu) == 0u) {
         pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
-        if (cur >= 0) quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+        if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb); }
       } else {
         push(REF_MARK);
         cur_inst = ii; cur = root;
@@ -1730,7 +1757,8 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
     if (f.out_rgba8) {
       // the reference's storage image really has the 8-bit surface format (src/main.cpp:1899): clamp to [0,1], scale, round
       auto q = [](float v) -> unsigned char { v = fminf(fmaxf(v, 0.0f), 1.0f); return (unsigned char)(v * 255.0f + 0.5f); };
-      reinterpret_cast<uchar4*>(f.out)[p] = make_uchar4(q(px.x), q(px.y), q(px.z), q(px.w));
+      // byte order of the surface: R8G8B8A8, or B8G8R8A8 — what surfaceFormatList[0] usually is (src/main.cpp:1204)
+      reinterpret_cast<uchar4*>(f.out)[p] = f.out_rgba8 == 2 ? make_uchar4(q(px.z), q(px.y), q(px.x), q(px.w)) : make_uchar4(q(px.x), q(px.y), q(px.z), q(px.w));
     } else {
       f.out[p] = px;
     }
@@ -1763,6 +1791,12 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
       else if (t == STAT_SHADOW) v = s_q[Q_SHADOW];
       else if (t == STAT_QUEUE1) v = s_q[1];
       else if (t == STAT_FAULT) v = ld_cursor(f.counters + CNT_FAULT);
+      else if (t == STAT_FAULT_TOTAL) {
+        // sticky: the frames of a context run one after another on its stream, so this is the only writer at any time
+        uint32_t total = f.fault_total ? f.fault_total[0] : 0u;
+        if (f.fault_total && ld_cursor(f.counters + CNT_FAULT) != 0u) { total++; f.fault_total[0] = total; }
+        v = total;
+      }
       else if (t == STAT_NODE_VISITS) v = cnt64(CNT_NODE_VISITS);
       else if (t == STAT_TRI_TESTS) v = cnt64(CNT_TRI_TESTS);
       else if (t == STAT_NODE_VISITS_SH) v = cnt64(CNT_NODE_VISITS_SH);
@@ -1876,8 +1910,16 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
 }
 
 int tail_blocks_per_cu() {
-  int n = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k_tail<false, false>, 256, 0) != hipSuccess) return 0;
+  // the smallest over the four instantiations: any of them may be the one in flight (counting, 4-ary records)
+  int n = 1 << 30, v = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<false, false>, 256, 0) != hipSuccess) return 0;
+  n = min(n, v);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<true, false>, 256, 0) != hipSuccess) return 0;
+  n = min(n, v);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<false, true>, 256, 0) != hipSuccess) return 0;
+  n = min(n, v);
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<true, true>, 256, 0) != hipSuccess) return 0;
+  n = min(n, v);
   return n;
 }
 

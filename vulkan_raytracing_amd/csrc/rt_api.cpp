@@ -11,6 +11,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <queue>
 #include <string>
 #include <vector>
@@ -32,6 +34,13 @@ static_assert(sizeof(rt_material) == sizeof(MaterialDev), "material mirrors out 
 namespace {
 
 thread_local std::string g_create_error;
+
+// Live contexts (frame slots) per device, over ALL scenes of the process: every one of them may have a k_tail launch in flight,
+// and the workgroups of all of them must be co-resident for their grid barriers to complete (rt::tail_grid).
+std::mutex g_live_mutex;
+std::map<int, int> g_live_slots;
+int live_slots_on(int device) { std::lock_guard<std::mutex> lk(g_live_mutex); auto it = g_live_slots.find(device); return it == g_live_slots.end() ? 0 : it->second; }
+void live_slots_add(int device, int d) { std::lock_guard<std::mutex> lk(g_live_mutex); g_live_slots[device] += d; }
 
 struct Mesh {
   rt_mesh_range range{};
@@ -144,7 +153,8 @@ struct rt_ctx {
   float4* d_out_own = nullptr;
   float4* h_out_pinned = nullptr;   // rt_trace_async: pinned host copy of the frame
   size_t pinned_capacity = 0;      // float4 pixels
-  bool out_rgba8 = false;          // "output_rgba8": frames are stored as 8-bit RGBA (4 bytes per pixel) instead of RGBA32F
+  bool out_rgba8 = false;          // "output_rgba8" / "output_bgra8": frames are stored as 8-bit (4 bytes per pixel) instead of RGBA32F
+  bool out_bgra = false;           // ... in the byte order of B8G8R8A8 surfaces (the usual surfaceFormatList[0], src/main.cpp:1204, 1899)
   bool async_pending = false;
   int async_w = 0, async_h = 0;
   uint32_t* d_counters = nullptr;   // TWO counter blocks: frame k uses block k & 1 and its last kernel zeroes the other one for frame k + 1
@@ -152,7 +162,8 @@ struct rt_ctx {
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
   bool grid_user_set = false;      // "trace_blocks_per_cu" was set explicitly: keep it
-  int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped at rt_create so that MAX_TAILS_IN_FLIGHT of them are always co-resident
+  int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped so that the tails of every live slot on the device are always co-resident
+  int tail_resident_per_cu = 0;
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
   int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
   int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
@@ -182,10 +193,16 @@ struct rt_ctx {
   rt_stats last{};
   bool frame_pending = false;
   hipStream_t frame_stream = nullptr;
-  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; } last_frame{};
+  // what the last enqueued frame was rendered from: a re-render after a k_tail fault must produce THAT frame, whatever
+  // rt_set_uniforms / rt_set_instances did since (the instance records and TLAS nodes of `parity` are still the frame's own
+  // as long as inst_gen[parity] has not moved: one later rt_set_instances writes the other parity)
+  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; } last_frame{};
+  uint64_t inst_gen[2] = {0, 0};  // bumped whenever the records of that parity are rewritten
   bool tail_disabled = false;    // a k_tail barrier gave up once: this context keeps to per-bounce launches from then on
   bool frame_rerendered = false; // collect_stats rendered the pending frame again (after a k_tail fault): copies of it are stale
   uint32_t tail_faults = 0;
+  uint32_t* d_fault_total = nullptr;   // device word, never reset: frames of this context whose k_tail gave up (k_resolve adds to it and
+  uint64_t faults_seen = 0;            // mirrors it into the statistics block, so a fault survives later frames' statistics)
   bool debug_force_tail_fault = false;   // rt_set_param "debug_force_tail_fault": treat the next k_tail frame as faulted (tests the fallback)
   uint32_t last_max_bounce = 0;
   uint64_t last_primary = 0;
@@ -251,10 +268,11 @@ size_t rt::ovf_elems(int trace_blocks, int tail_blocks, uint32_t stride) {
   return (size_t)std::max(trace_blocks, tail_blocks) * 256u * (size_t)stride;
 }
 // Grid of k_tail.  Its workgroups spin in a grid barrier, so every k_tail that can be in flight at once (one per frame
-// slot, up to MAX_TAILS_IN_FLIGHT on a GPU) must be co-resident: resident capacity / MAX_TAILS_IN_FLIGHT, a multiple of
-// N_SHARDS, at most TAIL_BLOCKS.  0 = the device is too small for the tail kernel (per-bounce launches are used).
-int rt::tail_grid(int n_cu, int resident_blocks_per_cu) {
-  const long cap = (long)n_cu * std::max(0, resident_blocks_per_cu) / MAX_TAILS_IN_FLIGHT;
+// slot: MAX_TAILS_IN_FLIGHT per scene, and every scene of the process on that GPU counts — live_slots) must be co-resident:
+// resident capacity / max(MAX_TAILS_IN_FLIGHT, live slots), a multiple of N_SHARDS, at most TAIL_BLOCKS.  0 = too many
+// slots (or too small a device) for the tail kernel: per-bounce launches are used.
+int rt::tail_grid(int n_cu, int resident_blocks_per_cu, int live_slots) {
+  const long cap = (long)n_cu * std::max(0, resident_blocks_per_cu) / std::max(MAX_TAILS_IN_FLIGHT, live_slots);
   long g = std::min<long>(TAIL_BLOCKS, cap);
   g -= g % N_SHARDS;
   return g >= N_SHARDS ? (int)g : 0;
@@ -559,6 +577,12 @@ int ensure_common(rt_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->cnt_parity = 0;
   }
+  if (!c->d_fault_total) {
+    HIP_TRY(c, hipMalloc((void**)&c->d_fault_total, sizeof(uint32_t)));
+    HIP_TRY(c, hipMemsetAsync(c->d_fault_total, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->faults_seen = 0;
+  }
   if (!c->h_hint) {
     HIP_TRY(c, hipHostMalloc((void**)&c->h_hint, CNT_MAX_BOUNCES * sizeof(uint32_t), hipHostMallocMapped));
     for (int b = 0; b < CNT_MAX_BOUNCES; b++) c->h_hint[b] = 0xFFFFFFFFu;   // unknown: the first frame takes one launch per bounce
@@ -613,10 +637,14 @@ struct Span {
   }
 };
 
-int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, float4* d_out, hipStream_t s, bool no_tail = false) {
+// `again`: render THIS frame once more (after a k_tail fault) from the state it was submitted with, without k_tail
+int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, float4* d_out, hipStream_t s, const rt_ctx::LastFrame* again = nullptr) {
   const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
-  c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting};
-  const UniformsDev& u = c->uni;
+  const bool no_tail = again != nullptr;
+  const SceneDev sc = again ? again->sc : scene_dev(c);
+  const UniformsDev u = again ? again->uni : c->uni;
+  const int frame_parity = again ? again->parity : c->parity;
+  if (!again) { c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting, sc, u, c->parity, c->inst_gen[c->parity]}; c->frame_rerendered = false; }
   if (u.samples_per_pixel == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "samplesPerPixel must be >= 1");
   if (u.max_bounce_count + 2 > (uint32_t)CNT_MAX_BOUNCES) return fail(c, RT_ERR_INVALID_ARGUMENT, "maxBounceCount too large (max 69)");
   const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
@@ -632,17 +660,16 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   FrameDev f = c->frame;
   // the counters of this frame were zeroed by the previous frame's k_resolve (or at allocation); this frame's k_resolve zeroes the other block
   f.counters = c->d_counters + (size_t)c->cnt_parity * CNT_WORDS; f.counters_next = c->d_counters + (size_t)(c->cnt_parity ^ 1) * CNT_WORDS;
-  f.ovf_stack = c->d_ovf; f.out = d_out; f.out_rgba8 = c->out_rgba8 ? 1 : 0; f.hint = c->d_hint; f.stats_out = c->d_stats;
+  f.ovf_stack = c->d_ovf; f.out = d_out; f.out_rgba8 = c->out_rgba8 ? (c->out_bgra ? 2 : 1) : 0; f.hint = c->d_hint; f.stats_out = c->d_stats; f.fault_total = c->d_fault_total;
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
-  const SceneDev sc = scene_dev(c);
   // Primary-ray coverage mask: on when the bands are whole 8x8 tiles, the camera basis is invertible and the scene has boxes.
   // The mask of this frame was cleared by the previous frame's k_resolve (or at allocation); this frame's clears the other.
   // Views: 0 = the camera; 1..6 = the faces of a cube around the light, when the shadow rays take entry lists (below).
   CoverViews cv{};
   CoverArgs& ca = cv.v[0];
   bool cover_on = c->primary_cover && rows > 0 && c->scene->max_cover_count > 0 && (n_shards == 1 || band_rows % 8 == 0) && c->cfg.variant != 1 &&
-                  c->h_inst.size() <= 65535;   // (k_cover's grid has one row of workgroups per instance)
+                  sc.n_inst <= 65535;   // (k_cover's grid has one row of workgroups per instance)
   if (cover_on) {
     const double R[9] = {u.right[0], u.up[0], u.forward[0], u.right[1], u.up[1], u.forward[1], u.right[2], u.up[2], u.forward[2]};   // columns right, up, forward
     const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
@@ -656,13 +683,13 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       for (int k = 0; k < 9; k++) ca.inv[k] = (float)inv[k];
       for (int k = 0; k < 3; k++) ca.cam[k] = u.position[k];
       ca.kf = 2.5f;   // src/shader.rgen:79
-      ca.width = W; ca.height = H; ca.tiles_x = (W + 7) / 8; ca.tiles_y = (H + 7) / 8; ca.n_inst = (int)c->h_inst.size();
+      ca.width = W; ca.height = H; ca.tiles_x = (W + 7) / 8; ca.tiles_y = (H + 7) / 8; ca.n_inst = sc.n_inst;
       ca.mask_offset = 0; ca.apex_radius = 0.0f;
       cv.n = 1;
     }
   }
   // Entry lists (k_entry) ride on the coverage mask: same tiles, same camera basis; the one-lane BVH2 kernel only.
-  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && c->h_inst.size() < ENTRY_NO_INST;
+  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && (uint32_t)sc.n_inst < ENTRY_NO_INST;
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
   const bool light_on = entry_on && c->shadow_entry && std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2]);
   const int LT = c->light_tiles;
@@ -742,7 +769,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
   c->last_empty = rows == 0;
   // the instance records / TLAS nodes of this slot were copied on the context's stream: a frame on another stream waits on the device
-  if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload[c->parity], 0));
+  if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload[c->parity], 0));   // (also orders a re-render behind newer uploads: harmless)
   if (rows == 0) return RT_OK;   // nothing is launched: both counter blocks stay zero
   c->cnt_parity ^= 1;
   if (f.cover_next) c->cover_parity ^= 1;   // (f.cover / f.cover_next were taken above)
@@ -769,14 +796,16 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         // workgroups (any count works: the bodies steal from the other shards) — the workgroups of k_tail hold their CU
         // resources while they wait at the grid barriers, so a 64-workgroup grid for the 260 secondary rays of a 1/8 shard
         // mostly waits (1/8 shard with 16 slots in flight: 0.100 ms with 64 workgroups, 0.091 with 8, 0.088 with 2)
-        int tb = c->tail_blocks;
+        // (contexts created since — other scenes on this GPU included — shrink every slot's share of the resident workgroups)
+        int tb = std::min(c->tail_blocks, tail_grid(c->n_cu, c->tail_resident_per_cu, live_slots_on(c->device)));
+        if (tb <= 0) { { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); } { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); } continue; }
         const uint32_t expect = ((volatile uint32_t*)c->h_hint)[b];
         // (a lone slot keeps the full grid: nobody else needs the room and 64 workgroups finish 2 k rays in 43 us, 9 in 55)
         if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !c->tail_full_grid && c->scene->members.size() >= 3) {
           long want = ((long)expect + 255) / 256;
           const long lo = c->tail_min_blocks;
           if (lo >= N_SHARDS) want = (want + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
-          tb = (int)std::min<long>(c->tail_blocks, std::max<long>(lo, want));
+          tb = (int)std::min<long>(tb, std::max<long>(lo, want));
         }
         Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, tb, s);
         break;
@@ -798,9 +827,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   }
   HIP_TRY(c, hipGetLastError());
   // the instance records / TLAS nodes of this parity are in use until here
-  if (!c->ev_frame[c->parity]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_frame[c->parity], hipEventDisableTiming));
-  HIP_TRY(c, hipEventRecord(c->ev_frame[c->parity], s));
-  c->ev_frame_valid[c->parity] = true;
+  if (!c->ev_frame[frame_parity]) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_frame[frame_parity], hipEventDisableTiming));
+  HIP_TRY(c, hipEventRecord(c->ev_frame[frame_parity], s));
+  c->ev_frame_valid[frame_parity] = true;
   return RT_OK;
 }
 
@@ -816,17 +845,31 @@ int collect_stats(rt_ctx* c) {
   if (!c->last_empty) {
     st.rays_secondary = hs[STAT_SECONDARY];
     st.rays_shadow = hs[STAT_SHADOW];
-    if (hs[STAT_FAULT] != 0 || (c->debug_force_tail_fault && !c->tail_disabled)) {
-      // A grid barrier of k_tail gave up (its workgroups were not co-resident: another process on the GPU, a partition
-      // smaller than the occupancy query promised).  The frame is incomplete: render it again with one launch per bounce
-      // and kernel, and keep this context off k_tail from now on.
+    // k_tail faults: the never-reset total tells of EVERY frame of this context whose grid barrier gave up (its workgroups were not
+    // co-resident: another process on the GPU, a partition smaller than the occupancy query promised) — also of frames enqueued
+    // before the last one, whose own statistics a later k_resolve has overwritten.  Any fault keeps this context off k_tail from
+    // now on; the frame that is re-rendered (one launch per bounce and kernel, from the state it was submitted with) is the LAST
+    // one: earlier frames of the stream have been overwritten in d_out by their successors or were the caller's to collect one
+    // by one (rt_api.h: "a frame is complete after the rt_synchronize / rt_get_stats / rt_trace_wait that follows it").
+    const uint64_t total = hs[STAT_FAULT_TOTAL];
+    const bool forced = c->debug_force_tail_fault && !c->tail_disabled;
+    if (total != c->faults_seen || forced) {
+      c->tail_faults += (uint32_t)(total - c->faults_seen) + ((forced && hs[STAT_FAULT] == 0) ? 1u : 0u);
+      c->faults_seen = total;
+      c->tail_disabled = true;
+    }
+    if (hs[STAT_FAULT] != 0 || forced) {
       c->debug_force_tail_fault = false;
-      c->tail_faults++; c->tail_disabled = true;
       const rt_ctx::LastFrame lf = c->last_frame;
+      if (c->inst_gen[lf.parity] != lf.inst_gen) {
+        c->frame_pending = false;
+        return fail(c, RT_ERR_DEVICE, "a k_tail grid barrier gave up and the frame cannot be rendered again: rt_set_instances replaced its instance records "
+                                      "twice before the frame was collected (collect every frame, or update the instances at most once per frame)");
+      }
       const bool counting = c->counting;
       c->counting = lf.counting;
       c->ev_used = 0; c->spans.clear(); c->timed_frames = 0;
-      int r = enqueue_frame(c, lf.W, lf.H, lf.band_rows, lf.shard, lf.n_shards, lf.d_out, c->frame_stream, true);
+      int r = enqueue_frame(c, lf.W, lf.H, lf.band_rows, lf.shard, lf.n_shards, lf.d_out, c->frame_stream, &lf);
       c->counting = counting;
       if (r) { c->frame_pending = false; return r; }
       c->frame_rerendered = true;
@@ -861,6 +904,7 @@ int collect_stats(rt_ctx* c) {
   }
   st.timed_frames = c->timed_frames;
   st.tail_faults = c->tail_faults;
+  st.frames_rerendered = c->frame_rerendered ? 1u : 0u;
   c->ev_used = 0; c->spans.clear(); c->timed_frames = 0;
   c->last = st;
   c->frame_pending = false;
@@ -914,7 +958,9 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
-  c->tail_blocks = tail_grid(c->n_cu, tail_blocks_per_cu());   // 0: device too small for k_tail's co-residency guarantee
+  c->tail_resident_per_cu = tail_blocks_per_cu();
+  live_slots_add(device_id, 1);
+  c->tail_blocks = tail_grid(c->n_cu, c->tail_resident_per_cu, live_slots_on(device_id));   // 0: device too small for k_tail's co-residency guarantee
   if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TAIL_MIN_BLOCKS")) c->tail_min_blocks = std::max(1, atoi(env));
   if (getenv("RT_TAIL_FULL_GRID")) c->tail_full_grid = true;
@@ -922,7 +968,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -946,10 +992,11 @@ int rt_create_frame_slot(rt_ctx* parent, rt_ctx** out_ctx) {
 
 void rt_destroy(rt_ctx* c) {
   if (!c) return;
+  live_slots_add(c->device, -1);
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e,
+  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e, c->d_fault_total,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
@@ -1061,6 +1108,9 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     int q = quiesce_scene(c); if (q) return q;
     int r = link_blas(c); if (r) return r;
   }
+  // from here on the slot's host-side TLAS state is being replaced: an error return leaves it INVALID (rt_set_instances
+  // has to be called again) instead of half old, half new
+  c->tlas_valid = false;
   c->h_inst.assign(inst, inst + n);
   std::vector<InstanceDev> inst_dev(n);
   std::vector<Aabb> boxes(n);
@@ -1101,6 +1151,7 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
                     " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
   c->parity = next_parity;
+  c->inst_gen[next_parity]++;
   int r = upload_instances(c, inst_dev); if (r) return r;
   c->tlas_valid = true;
   return RT_OK;
@@ -1231,7 +1282,12 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "output_rgba8") {
     if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "output_rgba8 must be 0 or 1");
     if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "output_rgba8 cannot change while a frame is pending");
-    c->out_rgba8 = value != 0; return RT_OK;
+    c->out_rgba8 = value != 0; c->out_bgra = false; return RT_OK;
+  }
+  if (k == "output_bgra8") {
+    if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "output_bgra8 must be 0 or 1");
+    if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "output_bgra8 cannot change while a frame is pending");
+    c->out_rgba8 = value != 0; c->out_bgra = value != 0; return RT_OK;
   }
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
@@ -1330,7 +1386,7 @@ int rt_debug_check_builders(const float* verts6, size_t n_floats, const uint32_t
 // allocation for that grid, a traversal grid of trace_blocks and ovf_stride entries per thread.
 int rt_debug_sizing(int n_cu, int resident_per_cu, int trace_blocks, uint32_t ovf_stride, uint64_t* out) {
   if (!out || n_cu <= 0 || trace_blocks <= 0) return RT_ERR_INVALID_ARGUMENT;
-  const int g = tail_grid(n_cu, resident_per_cu);
+  const int g = tail_grid(n_cu, resident_per_cu, 0);
   out[0] = (uint64_t)g; out[1] = (uint64_t)ovf_elems(trace_blocks, g, ovf_stride);
   return RT_OK;
 }

@@ -174,6 +174,8 @@ enum StatSlot : int {
   STAT_FAULT = 4,
   STAT_NODE_VISITS = 5, STAT_TRI_TESTS = 6, STAT_NODE_VISITS_SH = 7, STAT_TRI_TESTS_SH = 8,
   STAT_DIAG = 9,          // 6 values
+  STAT_FAULT_TOTAL = 15,  // frames of this context whose k_tail gave up, EVER (FrameDev::fault_total): unlike STAT_FAULT it survives the
+                          // statistics of later frames enqueued behind a faulted one
   STAT_WORDS = 16
 };
 constexpr int CNT_WORKS = CNT_TAILS + N_QUEUES * N_SHARDS * CNT_STRIDE;

@@ -42,10 +42,11 @@ struct FrameDev {
   uint32_t* counters_next;     // the context's other counter block: k_resolve (the frame's last kernel) zeroes it for the next frame
   int32_t* ovf_stack;          // SceneDev::ovf_stride ints per persistent thread
   unsigned long long* stats_out;   // host-mapped StatSlot block, written by k_resolve (NULL: not wanted)
+  uint32_t* fault_total;           // the context's never-reset count of frames whose k_tail gave up (device word)
   uint32_t* hint;              // host-mapped array [CNT_MAX_BOUNCES]: size of every bounce queue, written by k_resolve and
                                // read by the host, unsynchronised, as the launch-strategy hint for the next frame
   float4* out;                 // compact shard image (rows x W RGBA32F; rows x W RGBA8 when out_rgba8 is set)
-  int out_rgba8;
+  int out_rgba8;               // 0: RGBA32F, 1: R8G8B8A8, 2: B8G8R8A8
   uint32_t shard_cap;          // entries per queue shard (queues hold N_SHARDS * shard_cap rays)
   int width, height;           // full frame
   int rows;                    // rows rendered by this shard (compact)
@@ -131,6 +132,6 @@ int trace_threads_per_block();
 int tail_blocks_per_cu();
 // host-only sizing rules (rt_api.cpp)
 size_t ovf_elems(int trace_blocks, int tail_blocks, uint32_t stride);
-int tail_grid(int n_cu, int resident_blocks_per_cu);
+int tail_grid(int n_cu, int resident_blocks_per_cu, int live_slots);
 
 }  // namespace rt
