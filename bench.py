@@ -137,7 +137,10 @@ def cpu_baseline(wl, budget_s=14.0):
     S.set_skybox(wl.sky)
     W, H = wl.width, wl.height
     visible, quota = visible_cores()
-    cores = int(os.environ.get("RT_CPU_THREADS", visible))
+    # threads = the cores the process can really run on: min(visible cores, cgroup CPU quota rounded up) — 256 threads on a quota of
+    # 16 cores oversubscribe the oracle's tile queue and measured SLOWER than 16 (41.6 vs 46.4 Mrays/s)
+    usable = visible if not quota else max(1, min(visible, int(-(-quota // 1))))
+    cores = int(os.environ.get("RT_CPU_THREADS", usable))
     t0 = time.time()
     _, rc = S.render(W, H, threads=cores)
     one = max(time.time() - t0, 1e-3)
@@ -164,8 +167,9 @@ def cpu_baseline(wl, budget_s=14.0):
             "one_thread": {"value": rays1 / dt1 / 1e6, "unit": "Mrays/s", "cores": 1,
                            "sample": "%d x rows %d..%d of the frame (%d rays, %.1f s)" % (reps1, y0, y0 + 63, rays1, dt1)},
             "sample": "%d full %dx%d frames of the same workload (%d rays, %.1f s): oracle/rt_oracle.cpp built g++ -O3 -march=native -ffp-contract=off on this box, "
-                      "its own SAH BVH, %d threads = every core visible to the process (%s)"
-                      % (reps, W, H, rays, dt, cores, "cgroup CPU quota %.1f" % quota if quota else "no cgroup CPU quota")}
+                      "its own SAH BVH, %d threads = min(%d cores visible to the process, %s)"
+                      % (reps, W, H, rays, dt, cores, visible, "cgroup CPU quota %.1f rounded up" % quota if quota else "no cgroup CPU quota"),
+            "visible_cores": visible, "cgroup_cpu_quota": quota}
 
 
 class Rig:
@@ -560,6 +564,27 @@ def main(args):
                     roof["profile_note"] = "profiles/latest_profile.json was taken on another configuration or kernel source (%s): rocprof / traffic figures withheld" % json.dumps(prof.get("tag"))
             except Exception as e:   # noqa: BLE001
                 roof["profile_note"] = "profiles/latest_profile.json unreadable: %r" % (e,)
+        # the any-hit (shadow) traversal kernel, the other large one: same formula (48 B ray in, 16 B colour out), its live launch time
+        # from the all-kernels continuation of the timed loop
+        sh_live_s = st_all.ms_trace_shadow * 1e-3
+        sh_rate = sh_bytes / sh_live_s / 1e9 if sh_live_s > 0 else 0.0
+        roof["shadow_kernel"] = {"bound": "hbm", "achieved": sh_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_rate / HBM_PEAK_GBS,
+                                 "kernel": "any-hit traversal k_trace<shadow> (flags 13, src/shader.rgen:66-67,111-112) + the rgen:114-129 epilogue",
+                                 "avg_launch_ms": st_all.ms_trace_shadow, "algorithmic_bytes_per_launch": sh_bytes, "rays_per_frame_in_kernel": int(sh_rays),
+                                 "mean_node_visits_per_ray": cst.node_visits_shadow / max(1, sh_rays), "mean_tri_tests_per_ray": cst.tri_tests_shadow / max(1, sh_rays),
+                                 "timing": "HIP events, live, mean over the continuation loop's frames of slot 0 (events around every kernel)"}
+        result["mean_node_visits_per_closest_ray"] = mean_nodes
+        result["mean_node_visits_per_shadow_ray"] = cst.node_visits_shadow / max(1, sh_rays)
+        # what `value` is made of: most primary rays are shaded as misses inside k_raygen (coverage mask, empty entry records, TLAS
+        # boxes) and never enter a traversal kernel.  value_traversed counts only the rays that did.
+        if n == 1:
+            traversed = cst.closest_rays + cst.rays_shadow
+            result["value_traversed"] = traversed / (result["ms_per_step"] * 1e-3) / 1e6
+            result["rays_traversed_per_frame"] = {"closest_hit_kernels": int(cst.closest_rays), "shadow_kernel": int(cst.rays_shadow),
+                                                  "primary_rays_ended_in_raygen": int(rays_frame[0] - (cst.closest_rays - cst.rays_secondary)),
+                                                  "share_of_primary_rays_ended_in_raygen": (rays_frame[0] - (cst.closest_rays - cst.rays_secondary)) / max(1, rays_frame[0]),
+                                                  "definition": "value_traversed = (rays through k_trace<closest>/k_tail + rays through k_trace<shadow>) / ms_per_step, Mrays/s; "
+                                                                "value counts one ray per traceRayEXT-equivalent, including the primary rays whose miss k_raygen settles"}
         result["roofline"] = roof
         if last_frame is not None:
             img = last_frame.cpu().numpy()

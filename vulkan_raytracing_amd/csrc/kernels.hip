@@ -186,6 +186,11 @@ __device__ __forceinline__ bool quant_far(F3 qs, F3 qb) {
   const float K = 2097152.0f;   // 0.25 quantum / 2^-23
   return __builtin_fabsf(qb.x) > K * __builtin_fabsf(qs.x) || __builtin_fabsf(qb.y) > K * __builtin_fabsf(qs.y) || __builtin_fabsf(qb.z) > K * __builtin_fabsf(qs.z);
 }
+// the same test before the division by d: |q_lo - o| > K q_scale on some axis, against the smallest scale (3 VALU per ray space)
+__device__ __forceinline__ bool quant_far_o(F3 o, const float* q_lo, const float* q_scale) {
+  const float r = 2097152.0f * fminf(fminf(q_scale[0], q_scale[1]), q_scale[2]);
+  return fmaxf(fmaxf(__builtin_fabsf(q_lo[0] - o.x), __builtin_fabsf(q_lo[1] - o.y)), __builtin_fabsf(q_lo[2] - o.z)) > r;
+}
 __device__ __forceinline__ bool slab_q_far(uint32_t wx, uint32_t wy, uint32_t wz, F3 qs, F3 qb, uint3 rot, float tmin, float tlim, float& tn) {
   const float ex = 2.4e-7f * __builtin_fabsf(qb.x), ey = 2.4e-7f * __builtin_fabsf(qb.y), ez = 2.4e-7f * __builtin_fabsf(qb.z);
   wx = __builtin_amdgcn_alignbit(wx, wx, rot.x); wy = __builtin_amdgcn_alignbit(wy, wy, rot.y); wz = __builtin_amdgcn_alignbit(wz, wz, rot.z);
@@ -691,13 +696,13 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
       F3 qs, qb; uint3 rot;
       quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
-      const bool far = quant_far(qs, qb);   // a camera thousands of units from the scene: widened slab tests (see quant_far)
+      const bool far = quant_far(qs, qb);   // a camera hundreds of TLAS extents from the scene: the TLAS does not cull (see quant_far)
       // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
       const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
       const uint4 Q0 = rp[0], Q1 = rp[1];
       float tn;
-      const bool h0 = far ? slab_q_far(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn) : slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
-      const bool h1 = (far ? slab_q_far(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn) : slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn)) && Q1.w != Q1.z;
+      const bool h0 = far || slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
+      const bool h1 = (far || slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, 0.001f, 10000.0f, tn)) && Q1.w != Q1.z;
       const int c0 = (int)Q1.z, c1 = (int)Q1.w;
       survive = (h0 && c0 < 0) || (h1 && c1 < 0);
 #pragma unroll
@@ -706,8 +711,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
         if ((k ? h1 : h0) && ch >= 0 && !survive) {
           const uint4* np = reinterpret_cast<const uint4*>(sc.blas_nodes + ch);
           const uint4 N0 = np[0], N1 = np[1];
-          survive = far ? (slab_q_far(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q_far(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn))
-                        : (slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn));
+          survive = far || slab_q(N0.x, N0.y, N0.z, qs, qb, rot, 0.001f, 10000.0f, tn) || slab_q(N0.w, N1.x, N1.y, qs, qb, rot, 0.001f, 10000.0f, tn);
         }
       }
     }
@@ -779,6 +783,9 @@ constexpr int MODE_RAW = 2;      // o.w = tmin, d.w = tmax; writes HitRec
 #endif
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 5    /* waves per SIMD the shipped traversal kernels are register-allocated for (= workgroups per CU) */
+#endif
+#ifndef RT_LEAF_CHAIN
+#define RT_LEAF_CHAIN 1      /* leaves tested per visit of the leaf phase when leaf follows leaf on the stack */
 #endif
 #ifndef RT_STACK2_LDS
 #define RT_STACK2_LDS 12   /* 12 entries in LDS (3 KB per wave) let 6 blocks share a CU; deeper paths spill to HBM */
@@ -941,7 +948,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
       co = xform_point(m, wo); cd = xform_vec(m, wd);
       const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
-      quant_space(co, cd, qlo3, qsc3, qs, qb, rot); far = quant_far(qs, qb);
+      quant_space(co, cd, qlo3, qsc3, qs, qb, rot); far = quant_far_o(co, qlo3, qsc3);
     }
   };
 
@@ -970,9 +977,9 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             // current one, and the ray enters the record's instance here instead of in phase (C)
             uint32_t ent;
             if (MODE == MODE_SHADOW) ent = s_ent[wave][ci];
-            else { ent = __float_as_uint(ro.w); tmax = 10000.0f; }   // src/shader.rgen:87 (o.w carries the tile)
-            const bool rev_flag = (ent & ENTRY_REVERSE) != 0u;
-            ent &= ~ENTRY_REVERSE;
+            else ent = __float_as_uint(ro.w);   // (o.w carries the tile; tmax is the constant 10000 of src/shader.rgen:87)
+            const bool rev_flag = MODE == MODE_SHADOW && (ent & ENTRY_REVERSE) != 0u;
+            if (MODE == MODE_SHADOW) ent &= ~ENTRY_REVERSE;
             int4 r0 = make_int4((int)ENTRY_EMPTY, REF_DONE, 0, 0), r1 = make_int4(0, 0, 0, 0);
             if (ent != ENTRY_FROM_ROOT) {
               const int4* rp = reinterpret_cast<const int4*>(a.entry + ent);
@@ -980,14 +987,14 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             }
             const uint32_t hdr = (uint32_t)r0.x;
             if (ent == ENTRY_FROM_ROOT) {
-              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb);
+              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
               sp = 1; cur = a.sc.tlas_root;
             } else if (hdr == ENTRY_EMPTY) {
               sp = 1; cur = REF_DONE;   // nothing a ray of this tile can hit: the ray is finished (a miss)
             } else {
               const uint32_t nw = hdr & 15u, n_rm = (hdr >> 4) & 15u, ia = hdr >> 8;
               // ENTRY_REVERSE: the instance's subtrees in the opposite order (the farthest from the view point first)
-              const bool rev = rev_flag && nw > n_rm;
+              const bool rev = MODE == MODE_SHADOW && rev_flag && nw > n_rm;   // (camera records are never reversed: no such code in the closest-hit kernel)
               int cur_new = r0.y;
               const int wk[6] = {r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
@@ -999,15 +1006,16 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
               if (rev) stk[(1u + n_rm) * 64u] = r0.y;
               sp = 1 + (int)nw;
               cur = cur_new;
+              __builtin_amdgcn_sched_barrier(0);   // the record's words are on the stack before the instance record is fetched (register peak of the kernel)
               if (ia != ENTRY_NO_INST) { int root; uint32_t imask; to_instance((int)ia, root, imask); cur_inst = (int)ia; }   // (k_entry never names an invisible instance)
-              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb);
+              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
             }
           } else {
-            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb);
+            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
             sp = 1;
             cur = a.sc.tlas_root;   // TLAS root (always interior)
           }
-          best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
+          best_t = (ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
           need = false;
         }
         chunk_pos += n_need < avail ? n_need : avail;
@@ -1026,10 +1034,11 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           const uint4 X = np[0], Y = np[1], Z = np[2], R = np[3];
           if (COUNT) cnt_nodes++;
           float t0, t1, t2, t3;
-          const bool h0 = far ? slab_q_far(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0) : slab_q(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
-          const bool h1 = far ? slab_q_far(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1) : slab_q(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
-          const bool h2 = far ? slab_q_far(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2) : slab_q(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2);
-          const bool h3 = far ? slab_q_far(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3) : slab_q(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3);
+          bool h0 = far ? slab_q_far(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0) : slab_q(X.x, Y.x, Z.x, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+          bool h1 = far ? slab_q_far(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1) : slab_q(X.y, Y.y, Z.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+          bool h2 = far ? slab_q_far(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2) : slab_q(X.z, Y.z, Z.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t2);
+          bool h3 = far ? slab_q_far(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3) : slab_q(X.w, Y.w, Z.w, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t3);
+          if (far && cur_inst < 0) { h0 = h1 = h2 = h3 = true; t0 = t1 = t2 = t3 = 0.0f; }   // far ray in world space: the TLAS does not cull (see the BVH2 visit below)
           // entry distance with the entry number in its two low mantissa bits; a miss sorts last
           uint32_t k0 = h0 ? (__float_as_uint(t0) & ~3u) : 0xFFFFFFFFu;
           uint32_t k1 = h1 ? ((__float_as_uint(t1) & ~3u) | 1u) : 0xFFFFFFFFu;
@@ -1067,8 +1076,13 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
-        const bool h0 = far ? slab_q_far(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0) : slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
-        const bool h1 = far ? slab_q_far(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1) : slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+        // A far ray in WORLD space (quant_far): its canonical object-space twin (rounded once per instance) can deviate from it by
+        // more than the padding of the instance boxes, so the TLAS is not allowed to cull for it — every instance is entered and
+        // the BLAS tests, made on the object-space ray itself with the widened slabs, decide.
+        const bool open_all = far && cur_inst < 0;
+        bool h0 = open_all ? (Q0.x & 0xFFFFu) <= (Q0.x >> 16) : (far ? slab_q_far(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0) : slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0));
+        bool h1 = open_all ? (Q0.w & 0xFFFFu) <= (Q0.w >> 16) : (far ? slab_q_far(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1) : slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1));
+        if (open_all) { t0 = 0.0f; t1 = 0.0f; }
         if (h0 && h1) {
           const bool swap = t1 < t0;
           push(swap ? ch.x : ch.y);
@@ -1151,26 +1165,32 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     // next one in the same pass instead of waiting a whole pass for each step.
     PH_BEGIN(1)
     if (cur < 0 && cur > REF_MARK && cur_inst >= 0) {
-      // BLAS leaf: Moller-Trumbore on 48-byte packets
-      const uint32_t ref = (uint32_t)(~cur);
-      const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
-      for (uint32_t k = 0; k < count; k++) {
-        const float4* tp = a.sc.tris + (size_t)(first + k) * 3;
-        const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
-        if (COUNT) cnt_tris++;
-        float tt, uu, vv;
-        if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), (ANY ? best_t : tmax), tt, uu, vv)) {
-          if (ANY && MODE == MODE_SHADOW) best_inst = cur_inst;   // the shadow pipeline only asks WHETHER something was hit: no record to keep
-          else {
-            const int prim = (int)__float_as_uint(T2.y);
-            const bool better = (best_inst < 0) || (tt < best_t) ||
-                                (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
-            if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
+      // BLAS leaf: Moller-Trumbore on 48-byte packets.  The entry popped after a leaf is often a leaf again (the far child of a
+      // bottom node whose two children were both hit): up to RT_LEAF_CHAIN leaves are tested in one visit of this phase, instead of
+      // one outer pass each — passes, not node visits, are what a ray's life is counted in.
+      for (int chain = 0; chain < RT_LEAF_CHAIN; chain++) {
+        const uint32_t ref = (uint32_t)(~cur);
+        const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
+        for (uint32_t k = 0; k < count; k++) {
+          const float4* tp = a.sc.tris + (size_t)(first + k) * 3;
+          const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
+          if (COUNT) cnt_tris++;
+          float tt, uu, vv;
+          // (the closest-hit pipeline's primary rays all have tmax 10000, src/shader.rgen:87: a constant for the ENTRY kernel, not a register)
+          if (tri_test(T0, T1, T2, co, cd, (MODE == MODE_RAW ? tmin_ray : a.tmin), (ANY ? best_t : ((ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax)), tt, uu, vv)) {
+            if (ANY && MODE == MODE_SHADOW) best_inst = cur_inst;   // the shadow pipeline only asks WHETHER something was hit: no record to keep
+            else {
+              const int prim = (int)__float_as_uint(T2.y);
+              const bool better = (best_inst < 0) || (tt < best_t) ||
+                                  (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
+              if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
+            }
           }
         }
+        if (ANY && best_inst >= 0) { cur = REF_DONE; break; }   // any hit ends the ray (flags 13, src/shader.rgen:67)
+        pop();
+        if (!(cur < 0 && cur > REF_MARK)) break;
       }
-      if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
-      else pop();
     }
     PH_END(1)
     PH_BEGIN(2)
@@ -1179,7 +1199,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       // an interior TLAS node (a TLAS leaf sets up its own space, and the bottom sentinel ends the ray)
       cur_inst = -1;
       pop();
-      if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb); }
+      if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(wo, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }
     }
     PH_END(2)
     PH_BEGIN(3)
@@ -1190,7 +1210,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       to_instance(ii, root, imask);
       if ((imask & 0xFFu) == 0u) {
         pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
-        if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far(qs, qb); }
+        if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(wo, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }
       } else {
         push(REF_MARK);
         cur_inst = ii; cur = root;

@@ -169,7 +169,9 @@ struct rt_ctx {
   int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
   bool tail_full_grid = false;
   int entry_points = 1;          // 1: k_entry gives every covered tile a list of deep subtrees and its primary rays start there (result-identical)
-  int shadow_entry = 1;          // 1: ... and every tile of a cube around the light one for the shadow rays (needs entry_points)
+  int shadow_entry = 0;          // 1: ... and every tile of a cube around the light one for the shadow rays (needs entry_points).  Off by default:
+                                 // measured, it takes a third off the node visits of the shadow rays and nothing off the time of their kernel, while
+                                 // the six extra views cost every frame (and every 1/N shard of a frame) their k_cover / k_entry work
   int light_tiles = LIGHT_TILES_DEFAULT;   // tiles per side of a face of that cube
   EntryRec* d_entry = nullptr;   // one record per 8x8 tile of this slot's largest frame so far
   size_t entry_alloc_tiles = 0;
