@@ -1297,7 +1297,7 @@ def test_shadow_entry_points_are_result_identical(ctx):
             ctx.set_param("shadow_entry", on)
             img, st = ctx.trace(w, h, counting=True)
             out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.node_visits_shadow)
-        ctx.set_param("shadow_entry", 1)
+        ctx.set_param("shadow_entry", 0)
         assert out[1][1] == out[0][1]
         assert np.array_equal(out[1][0], out[0][0]), "shadow entry lists changed %d pixels" % int((out[1][0] != out[0][0]).any(axis=2).sum())
         return out
@@ -1321,7 +1321,7 @@ def test_shadow_entry_points_are_result_identical(ctx):
             assert np.array_equal(o[1][0], out[1][0])
         ctx.set_param("light_tiles", 128)
     finally:
-        ctx.set_param("shadow_entry", 1); ctx.set_param("light_tiles", 128)
+        ctx.set_param("shadow_entry", 0); ctx.set_param("light_tiles", 128)
         sp.set_uniforms(base_u)
     wl = workloads.make("cfg5", RES)
     wl.apply(ctx, sky=scenes.synthetic_skybox(64))
@@ -1491,7 +1491,7 @@ def test_far_origins_up_to_the_pipelines_tmax_and_beyond(ctx):
     take the generic visit with a per-axis widened slab test (kernels.hip quant_far): hit records must equal the oracle's brute
     force bit for bit from 20 to 20 000 units (twice the pipeline's tmax), closest hit and any hit, through instance transforms,
     a third of the rays nearly parallel to a coordinate axis; and a frame rendered from 5000 units away equals the oracle's."""
-    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 1, 1, ctx=ctx, time_param=0.3)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 1, 1, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.3)
     rng = np.random.default_rng(5)
     # (beyond ~4 x tmax a binary32 ray is too coarse for any claim: ulp(t) = 0.004 at 60 000 units, and 1 record in 30 000 still
     # differs there — out of the pipeline's reach, src/shader.rgen:86-87 ends every ray at 10 000)
