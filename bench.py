@@ -546,7 +546,8 @@ def main(args):
                               "traversal kernel' in the configuration `value` is quoted on" % P}
         # rocprofv3 figures are attached ONLY when the committed profile was taken on this very configuration and kernel source
         tag = {"workload": args.workload, "mesh": args.mesh, "variant": args.variant or 0, "n_gpus": n, "frames_in_flight": P, "kernels_sha16": kernels_sha16()}
-        prof_file = os.path.join(ROOT, "profiles", "latest_profile.json")
+        # one committed profile per workload: profiles/latest_profile.json is the headline's (cfg3), the others carry their name
+        prof_file = os.path.join(ROOT, "profiles", "latest_profile.json" if args.workload == "cfg3" else "latest_profile_%s.json" % args.workload)
         if os.path.exists(prof_file):
             try:
                 prof = json.load(open(prof_file))
@@ -560,10 +561,12 @@ def main(args):
                                                 "frac_of_peak": prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "profile": prof.get("traffic_source")}
                     if prof.get("limiter"):
                         roof["limiter"] = prof["limiter"]
+                    if prof.get("k_trace_shadow_avg_ms"):
+                        roof["shadow_rocprof"] = {"avg_launch_ms": prof["k_trace_shadow_avg_ms"], "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch_shadow")}
                 else:
-                    roof["profile_note"] = "profiles/latest_profile.json was taken on another configuration or kernel source (%s): rocprof / traffic figures withheld" % json.dumps(prof.get("tag"))
+                    roof["profile_note"] = "profiles/%s was taken on another configuration or kernel source (%s): rocprof / traffic figures withheld" % (os.path.basename(prof_file), json.dumps(prof.get("tag")))
             except Exception as e:   # noqa: BLE001
-                roof["profile_note"] = "profiles/latest_profile.json unreadable: %r" % (e,)
+                roof["profile_note"] = "profiles/%s unreadable: %r" % (os.path.basename(prof_file), e)
         # the any-hit (shadow) traversal kernel, the other large one: same formula (48 B ray in, 16 B colour out), its live launch time
         # from the all-kernels continuation of the timed loop
         sh_live_s = st_all.ms_trace_shadow * 1e-3
@@ -573,6 +576,11 @@ def main(args):
                                  "avg_launch_ms": st_all.ms_trace_shadow, "algorithmic_bytes_per_launch": sh_bytes, "rays_per_frame_in_kernel": int(sh_rays),
                                  "mean_node_visits_per_ray": cst.node_visits_shadow / max(1, sh_rays), "mean_tri_tests_per_ray": cst.tri_tests_shadow / max(1, sh_rays),
                                  "timing": "HIP events, live, mean over the continuation loop's frames of slot 0 (events around every kernel)"}
+        if roof.get("shadow_rocprof"):
+            k_ms = roof.pop("shadow_rocprof")
+            roof["shadow_kernel"]["rocprof"] = {"avg_launch_ms": k_ms["avg_launch_ms"], "achieved": sh_bytes / (k_ms["avg_launch_ms"] * 1e-3) / 1e9,
+                                                "frac": sh_bytes / (k_ms["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            roof["shadow_kernel"]["traffic"] = k_ms["hbm_bytes_per_launch"]
         result["mean_node_visits_per_closest_ray"] = mean_nodes
         result["mean_node_visits_per_shadow_ray"] = cst.node_visits_shadow / max(1, sh_rays)
         # what `value` is made of: most primary rays are shaded as misses inside k_raygen (coverage mask, empty entry records, TLAS

@@ -1524,3 +1524,41 @@ def test_far_origins_up_to_the_pipelines_tmax_and_beyond(ctx):
     ref, rc = sp.orc.render(200, 120)
     check_image(img, ref)
     assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2])) and st.rays_secondary > 100
+
+
+def test_packet_kernel_is_result_identical(ctx):
+    """k_packet (rt_set_param "packet_trace": one wavefront walks a 64-ray chunk together — wave-uniform stack, scalar node and
+    triangle loads, every lane tests every visited node) is an alternative traversal kernel for the primary and the shadow rays,
+    off by default because it measured slower.  A lane tests candidates its own ray would never have reached, so it only works
+    because results do not depend on the set or order of candidates tested: frames and ray counts equal the one-lane-per-ray
+    kernels', with and without entry records, for the shadow-ray records too, and record-level rays (incoherent: the worst case
+    for a packet) equal the oracle's brute force, closest hit and any hit."""
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 0, 4, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 328, 203
+    try:
+        base, st0 = ctx.trace(W, H)
+        for params in ({"packet_trace": 1}, {"packet_trace": 1, "entry_points": 0}, {"packet_trace": 1, "shadow_entry": 1}, {"packet_trace": 1, "primary_cover": 0}):
+            for k, v in params.items():
+                ctx.set_param(k, v)
+            img, st = ctx.trace(W, H)
+            assert np.array_equal(img, base), params
+            assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (st0.rays_primary, st0.rays_secondary, st0.rays_shadow)
+            for k in params:
+                ctx.set_param(k, {"packet_trace": 0, "entry_points": 1, "shadow_entry": 0, "primary_cover": 1}[k])
+        ref, rc = sp.orc.render(W, H)
+        check_image(base, ref)
+        rng = np.random.default_rng(11)
+        n = 20000
+        o = rng.normal(size=(n, 3)) * 6.0
+        d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+        rays = np.zeros((n, 8), np.float32); rays[:, 0:3] = o; rays[:, 3] = 0.001; rays[:, 4:7] = d; rays[:, 7] = 1e4
+        b = sp.orc.intersect(rays, use_bvh=False)
+        ctx.set_param("packet_trace", 2)
+        g, _ = ctx.intersect(rays)
+        assert ((g["prim"] == b["prim"]) & (g["inst"] == b["inst"]) & (g["t"].view(np.uint32) == b["t"].view(np.uint32))).all()
+        ga, _ = ctx.intersect(rays, any_hit=True)
+        assert np.array_equal(ga["inst"] >= 0, b["inst"] >= 0)
+    finally:
+        for k, v in {"packet_trace": 0, "entry_points": 1, "shadow_entry": 0, "primary_cover": 1}.items():
+            ctx.set_param(k, v)

@@ -22,7 +22,11 @@ def opt(n,d):
     return a[a.index(n)+1] if n in a else d
 print(json.dumps({'workload':opt('--workload','cfg3'),'mesh':opt('--mesh','standin'),'variant':int(opt('--variant',0)),'n_gpus':1,'frames_in_flight':int(opt('--frames-in-flight',4)),'kernels_sha16':bench.kernels_sha16()}))")
 export RT_PROFILE_SOURCE="profiles/${TAG}_rocprof_summary.txt (rocprofv3 --kernel-trace --stats -- python3 bench.py $ARGS)"
-python3 tools/summarize_profile.py $OUT --json $OUT/summary.json --latest $OUT/latest_profile.json > $OUT/summary.txt 2>&1
+WL=$(python3 -c "
+a=' $ARGS '.split()
+print(a[a.index('--workload')+1] if '--workload' in a else 'cfg3')")
+LATEST=latest_profile.json; [ "$WL" != "cfg3" ] && LATEST=latest_profile_$WL.json
+python3 tools/summarize_profile.py $OUT --json $OUT/summary.json --latest $OUT/$LATEST > $OUT/summary.txt 2>&1
 f=$(find $OUT/trace -name "*kernel_trace.csv" | head -1)
 python3 tools/timeline.py $f 0.3 >> $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -68,26 +68,46 @@ def main():
     # MI355X_MICROARCH.md §HBM: FETCH_SIZE is in KiB of 64-B requests and reads HALF the bytes of a wide
     # coalesced stream; WRITE_SIZE is exact) — both bounds are reported.
     pm = res.get("pmc", {})
-    for k in pm:
-        if ("k_trace<0, false, false" in k or "k_trace4<0, false, false" in k) and "FETCH_SIZE" in pm[k]:
-            fetch_kib = pm[k]["FETCH_SIZE"]
-            write_kib = pm[k].get("WRITE_SIZE", 0.0)
-            lo = (fetch_kib + write_kib) * 1024.0
-            hi = (2.0 * fetch_kib + write_kib) * 1024.0
-            res["hbm_bytes_per_launch_uncorrected"] = lo
-            res["hbm_bytes_per_launch"] = hi
-            print("closest-hit traversal: FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB per launch -> HBM bytes/launch %.3e (x2 read correction) / %.3e (raw)" % (fetch_kib, write_kib, hi, lo))
+
+    def is_closest(k):
+        return "k_trace<0, false, false" in k or "k_trace4<0, false, false" in k or "k_packet<0, false, false" in k
+
+    def is_shadow(k):
+        return "k_trace<1, true, false" in k or "k_trace4<1, true, false" in k or "k_packet<1, true, false" in k
+
+    def traffic(pred, label, key):
+        # the instantiation that does the work (entry records: k_trace<..., true>); a context's first frame also launches the plain one on its small later bounces
+        cands = [k for k in pm if pred(k) and "FETCH_SIZE" in pm[k]]
+        if not cands:
+            return
+        k = max(cands, key=lambda c: pm[c]["FETCH_SIZE"])
+        fetch_kib = pm[k]["FETCH_SIZE"]
+        write_kib = pm[k].get("WRITE_SIZE", 0.0)
+        lo = (fetch_kib + write_kib) * 1024.0
+        hi = (2.0 * fetch_kib + write_kib) * 1024.0
+        res[key + "_uncorrected"] = lo
+        res[key] = hi
+        print("%s (%s): FETCH_SIZE %.1f KiB, WRITE_SIZE %.1f KiB per launch -> HBM bytes/launch %.3e (x2 read correction) / %.3e (raw)" % (label, k, fetch_kib, write_kib, hi, lo))
+    traffic(is_closest, "closest-hit traversal", "hbm_bytes_per_launch")
+    traffic(is_shadow, "shadow traversal", "hbm_bytes_per_launch_shadow")
     if "--json" in sys.argv:
         json.dump(res, open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)
     # profiles/latest_profile.json: what bench.py attaches to its roofline block — only when its tag matches the run
     if "--latest" in sys.argv:
         out = sys.argv[sys.argv.index("--latest") + 1]
         tag = json.loads(os.environ.get("RT_PROFILE_TAG", "{}"))
-        closest = [v for k, v in tr.items() if "k_trace<0, false, false" in k or "k_trace<(int)0, (bool)0, (bool)0" in k]
-        durs = sorted(closest[0]) if closest else []
-        big = [x for x in durs if x >= 0.5 * durs[-1]] if durs else []      # the bounce-0 launches (a context's first frame also launches small later bounces)
+        def big_launches(pred):
+            cands = [sorted(v) for k, v in tr.items() if pred(k)]
+            if not cands:
+                return []
+            durs = max(cands, key=lambda d: sum(d))     # the instantiation that does the work
+            return [x for x in durs if x >= 0.5 * durs[-1]]   # its full-size launches (a context's first frame also launches small later bounces)
+        big = big_launches(lambda k: is_closest(short(k)) or is_closest(k))
+        big_sh = big_launches(lambda k: is_shadow(short(k)) or is_shadow(k))
         latest = {"tag": tag, "source": os.environ.get("RT_PROFILE_SOURCE", base),
                   "k_trace_closest_avg_ms": (sum(big) / len(big) / 1e3) if big else None, "k_trace_closest_launches": len(big),
+                  "k_trace_shadow_avg_ms": (sum(big_sh) / len(big_sh) / 1e3) if big_sh else None, "k_trace_shadow_launches": len(big_sh),
+                  "hbm_bytes_per_launch_shadow": res.get("hbm_bytes_per_launch_shadow"),
                   "hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "hbm_bytes_per_launch_uncorrected": res.get("hbm_bytes_per_launch_uncorrected"),
                   "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernels serialised by the profiler), read side doubled per MI355X_MICROARCH.md (HBM)",
                   "limiter": os.environ.get("RT_PROFILE_LIMITER")}

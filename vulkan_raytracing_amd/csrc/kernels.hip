@@ -722,7 +722,19 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   }
   // workgroups are handed to the XCDs round-robin in linear order
   const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & (N_SHARDS - 1);
-  const uint32_t slot = wave_alloc(survive, f.counters + cnt_tail(0, (int)shard));
+  // ONE allocation per workgroup: the survivors of a tile's (up to four) samples form one run of the queue, so the 64-ray chunks
+  // the traversal kernels pull hold rays of one tile (two where a run ends) — what the packet kernel's coherence rests on
+  __shared__ uint32_t s_run[5];
+  const uint64_t smask = __ballot(survive);
+  if (lane == 0) s_run[threadIdx.y] = (uint32_t)__builtin_popcountll(smask);
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0) {
+    uint32_t tot = 0;
+    for (uint32_t w = 0; w < blockDim.y; w++) { const uint32_t c = s_run[w]; s_run[w] = tot; tot += c; }
+    s_run[4] = tot ? atomicAdd(f.counters + cnt_tail(0, (int)shard), tot) : 0u;
+  }
+  __syncthreads();
+  const uint32_t slot = s_run[4] + s_run[threadIdx.y] + prefix_rank(smask);
   if (survive) {
     const uint32_t v = shard * f.shard_cap + slot;
     // (with entry lists the ray carries its tile instead of tmax, which is the constant 10000 of src/shader.rgen:87)
@@ -1267,6 +1279,249 @@ template <int MODE, bool ANY, bool WIDE, bool ENTRY = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU))) void k_trace(TraceArgs a) { trace_body<MODE, ANY, false, WIDE, ENTRY>(a); }
 template <int MODE, bool ANY, bool WIDE, bool ENTRY = false>
 __global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY>(a); }
+
+// ------------------------------------------------------------------------------------------------
+// k_packet: PACKET traversal — one wavefront walks one 64-ray chunk TOGETHER.  The rays of a chunk are coherent by
+// construction: primary rays of one 8x8 tile (k_raygen appends a tile's four samples in one run), shadow rays of neighbouring
+// hit points towards one light.  So the wave keeps ONE stack (a wave-uniform stack pointer in an SGPR, the entries in the lanes
+// of one VGPR: v_writelane / v_readlane), visits ONE node at a time, and every lane tests ITS ray against the node's two child
+// boxes; the wave descends where any lane wants to (near child by majority vote) and skips what no lane can hit.  What this
+// buys over one lane per ray (trace_body):
+//   * no divergence: every VALU instruction works for 64 rays, there are no phases and no waiting for the slowest lane's leaf;
+//   * node, triangle and instance records are wave-uniform: they come through the SCALAR cache (s_load_dwordx8 / x4) into
+//     SGPRs — one request per wave and visit instead of 64 lane requests to the vector memory path;
+//   * no LDS at all and ~60 VGPRs: eight waves per SIMD hide the scalar-load latency.
+// A lane tests nodes its own ray would never have reached (the union of the chunk's walks is visited), so results must not
+// depend on the order or the set of candidates tested — and they do not: the closest hit is the minimum over ALL accepted
+// candidates with the (instance, primitive) tie rule, an any-hit query only asks whether one exists.
+// Entry records (k_entry) start the walk of the lanes that share a tile; a chunk that straddles tiles is walked tile by tile.
+typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(4))) const u32x8 k_u32x8;   // constant address space: a uniform address loads through the scalar cache
+typedef __attribute__((address_space(4))) const u32x4 k_u32x4;
+__device__ __forceinline__ u32x8 sload8(const void* p) { return *(const k_u32x8*)(uintptr_t)p; }
+__device__ __forceinline__ u32x4 sload4(const void* p) { return *(const k_u32x4*)(uintptr_t)p; }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+// lane `sel` (wave-uniform) of `reg` := the wave-uniform value v
+__device__ __forceinline__ int lane_write(int reg, int v, int sel) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  // (v_writelane takes one SGPR besides the lane select in M0 — two SGPRs would exceed gfx9's constant bus; M0 is saved and restored)
+  int keep;
+  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(reg), "=&s"(keep) : "s"(v), "s"(sel));
+#endif
+  return reg;
+}
+
+template <int MODE, bool ANY, bool COUNT, bool ENTRY>
+__global__ __launch_bounds__(256) void k_packet(TraceArgs a) {
+  {
+    uint32_t total = 0;
+#pragma unroll
+    for (int t = 0; t < N_SHARDS; t++) total += ld_cursor(a.tails + t * CNT_STRIDE);
+    uint32_t want = (total + 256u * a.rays_per_lane - 1u) / (256u * a.rays_per_lane);
+    want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
+    if (want < a.min_blocks) want = a.min_blocks;
+    if (blockIdx.x >= want) return;
+  }
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
+  uint64_t cnt_nodes = 0, cnt_tris = 0, wave_nodes = 0, wave_tris = 0;   // per lane: what its own ray enters; per wave (lane 0): what the packet visits
+  const uint64_t diag_t0 = COUNT ? __builtin_readcyclecounter() : 0;
+  const char* const node_bytes = reinterpret_cast<const char*>(a.sc.blas_nodes);
+  const char* const inst_bytes = reinterpret_cast<const char*>(a.sc.inst);
+  for (;;) {
+    // ---- next 64-ray chunk of the sharded queues (wave-uniform)
+    uint32_t base = 0, count = 0;
+    while (tried < (uint32_t)N_SHARDS) {
+      const uint32_t size = ld_cursor(a.tails + shard * CNT_STRIDE);
+      uint32_t off = 0;
+      if (lane == 0 && size) off = atomicAdd(a.work + shard * CNT_STRIDE, 64u);
+      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
+      if (size && off < size) { base = shard * a.shard_cap + off; count = (size - off) < 64u ? (size - off) : 64u; break; }
+      shard = (shard + 1u) & (N_SHARDS - 1); tried++;
+    }
+    if (count == 0) break;
+    const bool on = lane < count;
+    const uint32_t q = base + lane;
+    float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
+    if (on) { ro = a.ray_o[q]; rd = a.ray_d[q]; }
+    const float tmin = MODE == MODE_RAW ? ro.w : a.tmin;
+    const float tmax = MODE == MODE_RAW ? rd.w : ((ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : ro.w);   // (ENTRY closest: o.w carries the tile)
+    const F3 wo = mk3(ro.x, ro.y, ro.z), wd = mk3(rd.x, rd.y, rd.z);
+    float best_t = tmax, best_u = 0.f, best_v = 0.f;
+    int best_prim = -1, best_inst = -1;
+    uint32_t ent = ENTRY_FROM_ROOT;
+    if (ENTRY) ent = MODE == MODE_SHADOW ? (on ? a.sh_e[q] : ENTRY_FROM_ROOT) : __float_as_uint(ro.w);
+
+    uint64_t todo = __ballot(on);
+    while (todo != 0ull) {
+      // ---- the lanes that share an entry record (without records: everybody) walk together
+      uint64_t grp = todo;
+      uint32_t e0 = ENTRY_FROM_ROOT;
+      if (ENTRY) {
+        e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)__builtin_ctzll(todo));
+        grp = __ballot(on && ((todo >> lane) & 1ull) != 0ull && ent == e0);
+      }
+      todo &= ~grp;
+      bool alive = ((grp >> lane) & 1ull) != 0ull;   // any-hit: cleared once the lane has its hit
+
+      F3 co = wo, cd = wd, qs, qb; uint3 rot;
+      quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+      bool far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
+      int sp = 0, stk0 = 0, stk1 = 0;   // wave stack: entry e lives in lane e of stk0 (e < 64) / lane e - 64 of stk1
+      auto push = [&](int v) {
+        if (sp < 64) stk0 = lane_write(stk0, v, sp); else stk1 = lane_write(stk1, v, sp - 64);
+        sp++;
+      };
+      auto pop = [&]() -> int {
+        if (sp == 0) return REF_DONE;
+        sp--;
+        return sp < 64 ? __builtin_amdgcn_readlane(stk0, sp) : __builtin_amdgcn_readlane(stk1, sp - 64);
+      };
+      int cur = a.sc.tlas_root, cur_inst = -1;
+      // ray -> object space of instance ii (all lanes, uniform instance); returns false for an instance the ray mask cannot see
+      auto enter = [&](int ii, int& root) -> bool {
+        const char* ip = inst_bytes + (size_t)ii * sizeof(InstanceDev);
+        const u32x8 A = sload8(ip + 96);        // blas_root, mask, custom_index, first_float, first_index, blas_root4, q_lo[0], q_lo[1]
+        if ((A[1] & 0xFFu) == 0u) return false;
+        const u32x4 B = sload4(ip + 128);       // q_lo[2], q_scale[0..2]
+        const u32x8 M0 = sload8(ip);            // w2o rows 0, 1
+        const u32x4 M1 = sload4(ip + 32);       // w2o row 2
+        const float m[12] = {u2f(M0[0]), u2f(M0[1]), u2f(M0[2]), u2f(M0[3]), u2f(M0[4]), u2f(M0[5]), u2f(M0[6]), u2f(M0[7]), u2f(M1[0]), u2f(M1[1]), u2f(M1[2]), u2f(M1[3])};
+        co = xform_point(m, wo); cd = xform_vec(m, wd);
+        const float qlo3[3] = {u2f(A[6]), u2f(A[7]), u2f(B[0])}, qsc3[3] = {u2f(B[1]), u2f(B[2]), u2f(B[3])};
+        quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
+        far = quant_far_o(co, qlo3, qsc3);
+        root = (int)A[0];
+        return true;
+      };
+      if (ENTRY && e0 != ENTRY_FROM_ROOT) {
+        const u32x8 R = sload8(a.entry + (e0 & ~ENTRY_REVERSE));
+        const uint32_t hdr = R[0];
+        if (hdr == ENTRY_EMPTY) continue;   // nothing a ray of this tile can hit
+        const uint32_t nw = hdr & 15u, n_rm = (hdr >> 4) & 15u, ia = hdr >> 8;
+        const int w[6] = {(int)R[2], (int)R[3], (int)R[4], (int)R[5], (int)R[6], (int)R[7]};
+        if ((e0 & ENTRY_REVERSE) != 0u && nw > n_rm) {
+          // the instance's subtrees in the opposite order: [words below] [old first node] [the rest, top to bottom]; walk starts at the bottom one
+#pragma unroll
+          for (uint32_t k = 0; k < 6u; k++) if (k < n_rm) push(w[k]);
+          push((int)R[1]);
+#pragma unroll
+          for (int k = 5; k >= 1; k--) if ((uint32_t)k < nw && (uint32_t)k > n_rm) push(w[k]);
+          cur = n_rm == 0u ? w[0] : n_rm == 1u ? w[1] : n_rm == 2u ? w[2] : n_rm == 3u ? w[3] : n_rm == 4u ? w[4] : w[5];
+        } else {
+#pragma unroll
+          for (uint32_t k = 0; k < 6u; k++) if (k < nw) push(w[k]);
+          cur = (int)R[1];
+        }
+        if (ia != ENTRY_NO_INST) { int root; enter((int)ia, root); cur_inst = (int)ia; }   // (k_entry never names an invisible instance; the record holds the marker)
+      }
+
+      for (;;) {
+        if (cur >= 0) {
+          // ---- interior node: one scalar fetch, every lane tests both children
+          const u32x8 Q = sload8(node_bytes + ((size_t)(uint32_t)cur << 5));
+          const int c0 = (int)Q[6], c1 = (int)Q[7];
+          const bool any_far = __ballot(alive && far) != 0ull;
+          float t0 = 0.f, t1 = 0.f;
+          bool h0, h1;
+          if (any_far && cur_inst < 0) {   // far rays in world space: the TLAS does not cull (see quant_far)
+            h0 = alive && (Q[0] & 0xFFFFu) <= (Q[0] >> 16); h1 = alive && (Q[3] & 0xFFFFu) <= (Q[3] >> 16);
+          } else if (any_far) {
+            h0 = alive && slab_q_far(Q[0], Q[1], Q[2], qs, qb, rot, tmin, best_t, t0);
+            h1 = alive && slab_q_far(Q[3], Q[4], Q[5], qs, qb, rot, tmin, best_t, t1);
+          } else {
+            h0 = alive && slab_q(Q[0], Q[1], Q[2], qs, qb, rot, tmin, best_t, t0);
+            h1 = alive && slab_q(Q[3], Q[4], Q[5], qs, qb, rot, tmin, best_t, t1);
+          }
+          const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
+          if (COUNT && lane == 0) wave_nodes++;
+          if (COUNT) {   // a lane "visits" the children its own ray enters (what one lane per ray would have visited)
+            if (h0) { if (c0 >= 0 || cur_inst < 0) cnt_nodes++; else cnt_tris += ((uint32_t)(~c0) & 7u) + 1u; }
+            if (h1) { if (c1 >= 0 || cur_inst < 0) cnt_nodes++; else cnt_tris += ((uint32_t)(~c1) & 7u) + 1u; }
+          }
+          if (m0 != 0ull && m1 != 0ull) {
+            const uint64_t pref1 = __ballot(h1 && (!h0 || t1 < t0));   // lanes that would take child 1 first
+            const bool first1 = 2 * __builtin_popcountll(pref1) > __builtin_popcountll(m0 | m1);
+            push(first1 ? c0 : c1);
+            cur = first1 ? c1 : c0;
+          } else if (m0 != 0ull) cur = c0;
+          else if (m1 != 0ull) cur = c1;
+          else cur = pop();
+        } else if (cur == REF_DONE) {
+          break;
+        } else if (cur == REF_MARK) {
+          // leave the instance: world space again
+          cur_inst = -1;
+          co = wo; cd = wd;
+          quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
+          far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
+          cur = pop();
+        } else if (cur_inst < 0) {
+          // TLAS leaf: enter the instance
+          const int ii = ~cur;
+          int root = 0;
+          if (enter(ii, root)) { push(REF_MARK); cur_inst = ii; cur = root; }
+          else cur = pop();
+        } else {
+          // BLAS leaf: every lane tests the leaf's triangles
+          const uint32_t ref = (uint32_t)(~cur);
+          const uint32_t first = ref >> 3, n_tri = (ref & 7u) + 1u;
+          if (COUNT && lane == 0) wave_tris += n_tri;
+          for (uint32_t k = 0; k < n_tri; k++) {
+            const char* tp = reinterpret_cast<const char*>(a.sc.tris) + (size_t)(first + k) * 48u;
+            const u32x8 TA = sload8(tp);        // 32-byte aligned for even packets only: two x4 loads are always legal
+            const u32x4 TB = sload4(tp + 32);
+            const float4 T0 = make_float4(u2f(TA[0]), u2f(TA[1]), u2f(TA[2]), u2f(TA[3])), T1 = make_float4(u2f(TA[4]), u2f(TA[5]), u2f(TA[6]), u2f(TA[7]));
+            const float4 T2 = make_float4(u2f(TB[0]), u2f(TB[1]), u2f(TB[2]), u2f(TB[3]));
+            float tt, uu, vv;
+            if (alive && tri_test(T0, T1, T2, co, cd, tmin, (ANY ? best_t : tmax), tt, uu, vv)) {
+              if (ANY) { best_inst = cur_inst; best_t = tt; best_u = uu; best_v = vv; best_prim = (int)TB[1]; alive = false; }   // any hit ends this lane's ray (flags 13, src/shader.rgen:67)
+              else {
+                const int prim = (int)TB[1];
+                const bool better = (best_inst < 0) || (tt < best_t) ||
+                                    (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
+                if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
+              }
+            }
+          }
+          if (ANY && __ballot(alive) == 0ull) break;   // every ray of the group has its hit
+          cur = pop();
+        }
+      }
+    }
+    // ---- results: one coalesced store per lane
+    if (on) {
+      if (MODE == MODE_CLOSEST) { a.hit_a[q] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim)); a.hit_inst[q] = best_inst; }
+      else if (MODE == MODE_SHADOW) {
+        // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
+        float cr = 0.08f, cg = 0.24f, cb = 0.08f;
+        if (best_inst < 0 || a.sc.n_materials != 0) {
+          const float4 shc = a.sh_c[q];
+          if (best_inst < 0) { cr = shc.x; cg = shc.y; cb = shc.z; }
+          else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); cr = amb.x; cg = amb.y; cb = amb.z; }
+        }
+        a.sample_color[__float_as_uint(rd.w)] = make_float4(cr, cg, cb, 1.0f);
+      } else { HitRec h; h.t = best_t; h.u = best_u; h.v = best_v; h.prim = best_prim; h.inst = best_inst; a.raw_out[q] = h; }
+    }
+  }
+  if (COUNT) {
+    for (int off = 32; off > 0; off >>= 1) {
+      cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
+      cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
+    }
+    if (lane == 0) {
+      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
+      // diag = (nodes the packets visited, triangles the packets tested, wave cycles): wave-level work, against the per-ray counts above
+      const int dg = ANY ? CNT_DIAG_SH : CNT_DIAG;
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg), (unsigned long long)wave_nodes);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 2), (unsigned long long)wave_tris);
+      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 4), (unsigned long long)(__builtin_readcyclecounter() - diag_t0));
+    }
+  }
+}
 
 // ---- variant 1: quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
 // 64-lane wavefront.
@@ -1886,6 +2141,20 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
   TraceArgs a = make_args(sc, f.counters, bounce, f.shard_cap, f.ovf_stack);
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
+  if (bounce == 0 && cfg.packet != 0 && cfg.variant == 0) {
+    // one wavefront per chunk of primary rays (k_packet); with entry records the walk of each tile's rays starts at its record
+    a.entry = f.entry;
+    a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
+    const dim3 g(cfg.packet_blocks), b(256);
+    if (f.entry != nullptr) {
+      if (counting) hipLaunchKernelGGL((k_packet<MODE_CLOSEST, false, true, true>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((k_packet<MODE_CLOSEST, false, false, true>), g, b, 0, s, a);
+    } else {
+      if (counting) hipLaunchKernelGGL((k_packet<MODE_CLOSEST, false, true, false>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((k_packet<MODE_CLOSEST, false, false, false>), g, b, 0, s, a);
+    }
+    return;
+  }
   if (bounce == 0 && f.entry != nullptr && cfg.variant == 0) {
     // primary rays start at their tile's entry record (k_entry)
     a.entry = f.entry;
@@ -1909,6 +2178,21 @@ void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, c
   TraceArgs a = make_args(sc, f.counters, Q_SHADOW, f.shard_cap, f.ovf_stack);
   a.ray_o = f.sh_o; a.ray_d = f.sh_d; a.sh_c = f.sh_c;
   a.sample_color = f.sample_color;
+  if (cfg.packet != 0 && cfg.variant == 0) {
+    // one wavefront per chunk of shadow rays (k_packet); optionally from the records of the cube around the light
+    const bool le = f.light_entry != nullptr && f.sh_e != nullptr;
+    a.entry = le ? f.light_entry : nullptr; a.sh_e = le ? f.sh_e : nullptr;
+    a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
+    const dim3 g(cfg.packet_blocks), b(256);
+    if (le) {
+      if (counting) hipLaunchKernelGGL((k_packet<MODE_SHADOW, true, true, true>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((k_packet<MODE_SHADOW, true, false, true>), g, b, 0, s, a);
+    } else {
+      if (counting) hipLaunchKernelGGL((k_packet<MODE_SHADOW, true, true, false>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((k_packet<MODE_SHADOW, true, false, false>), g, b, 0, s, a);
+    }
+    return;
+  }
   if (f.light_entry != nullptr && f.sh_e != nullptr && cfg.variant == 0) {
     // shadow rays start at the record of their tile of the cube around the light (k_entry, k_shade)
     a.entry = f.light_entry; a.sh_e = f.sh_e;
@@ -1925,6 +2209,13 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
                       int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, counters, 0, shard_cap, ovf_stack);
   a.ray_o = ray_o; a.ray_d = ray_d; a.raw_out = out;
+  if (cfg.packet >= 2 && cfg.variant == 0) {
+    a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
+    const dim3 g(cfg.packet_blocks), b(256);
+    if (any_hit) { if (counting) hipLaunchKernelGGL((k_packet<MODE_RAW, true, true, false>), g, b, 0, s, a); else hipLaunchKernelGGL((k_packet<MODE_RAW, true, false, false>), g, b, 0, s, a); }
+    else { if (counting) hipLaunchKernelGGL((k_packet<MODE_RAW, false, true, false>), g, b, 0, s, a); else hipLaunchKernelGGL((k_packet<MODE_RAW, false, false, false>), g, b, 0, s, a); }
+    return;
+  }
   if (any_hit) launch_trace<MODE_RAW, true>(a, counting, cfg, s);
   else launch_trace<MODE_RAW, false>(a, counting, cfg, s);
 }

@@ -960,6 +960,12 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
+  // k_packet (one wavefront per 64-ray chunk) is built and tested but OFF: measured slower (cfg3 lone frame 1.47 vs 0.95 ms;
+  // profiles/r03_experiments.txt) — a packet visits the union of its rays' walks, 63 nodes + 33 triangles per 64 primary rays,
+  // and its wave-uniform control flow runs on the CU's single scalar unit
+  c->cfg.packet = 0; c->cfg.packet_blocks = c->n_cu * 8;
+  if (const char* env = getenv("RT_PACKET")) c->cfg.packet = std::max(0, std::min(2, atoi(env)));
+  if (const char* env = getenv("RT_PACKET_BLOCKS_PER_CU")) { const int v = atoi(env); if (v > 0 && v <= 16) c->cfg.packet_blocks = c->n_cu * v; }
   c->tail_resident_per_cu = tail_blocks_per_cu();
   live_slots_add(device_id, 1);
   c->tail_blocks = tail_grid(c->n_cu, c->tail_resident_per_cu, live_slots_on(device_id));   // 0: device too small for k_tail's co-residency guarantee
@@ -1293,6 +1299,8 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   }
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
+  if (k == "packet_trace") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2"); c->cfg.packet = value; return RT_OK; }
+  if (k == "packet_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_blocks_per_cu must be 1..16"); c->cfg.packet_blocks = c->n_cu * value; return RT_OK; }
   if (k == "shadow_entry") { c->shadow_entry = value != 0; return RT_OK; }
   if (k == "light_tiles") {
     if (value < 8 || value > 512) return fail(c, RT_ERR_INVALID_ARGUMENT, "light_tiles must be 8..512");

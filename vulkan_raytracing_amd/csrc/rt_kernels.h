@@ -105,6 +105,9 @@ struct LaunchCfg {
   int rays_per_lane;           // device-side grid sizing of the traversal kernels (see k_trace)
   int min_blocks;
   int variant;                 // 0: BVH2, one lane per ray; 1: BVH4, four lanes per ray; 2: 4-ary records, one lane per ray
+  int packet;                  // variant 0 only.  1: the primary rays (bounce 0) and the shadow rays are walked by k_packet, one wavefront per
+                               // 64-ray chunk; 2: the record-level entry (rt_intersect) too (tests: incoherent rays through the packet kernel)
+  int packet_blocks;           // persistent grid of k_packet (no LDS, few registers: eight workgroups per CU fit)
 };
 
 size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
