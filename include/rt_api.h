@@ -223,7 +223,14 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
  * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357), 0 = host binned-SAH;
  * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids; "primary_cover" 1 (default) = before ray generation the
  * frontier boxes of every instance's BLAS are projected onto 8x8-pixel screen tiles and the samples of tiles no mesh can
- * project onto are shaded as misses without any box test, 0 = every primary ray is tested against the TLAS.
+ * project onto are shaded as misses without any box test, 0 = every primary ray is tested against the TLAS;
+ * "entry_points" 1 (default; needs primary_cover) = every marked tile gets an entry record — the handful of deep subtrees of the
+ * TLAS / the nearest instance's BLAS that the tile's beam of primary rays can touch — and its primary rays start their walk there
+ * instead of at the TLAS root; "shadow_entry" 1 = the same for the shadow rays, from the tiles of a cube of "light_tiles" (8..512,
+ * default 128) tiles per side around the light (default 0: measured no faster); "packet_trace" 1 = primary and shadow rays are
+ * walked by the packet kernel (one wavefront per 64-ray chunk; default 0: measured slower), 2 = rt_intersect's rays too;
+ * "output_bgra8" 1 = like "output_rgba8" in the byte order of a B8G8R8A8 surface (surfaceFormatList[0] is normally that,
+ * src/main.cpp:1204, 1899), so that a frame can be compared byte for byte with a screenshot of the original's swapchain image.
  * Results do not depend on any of them. */
 int rt_set_param(rt_ctx* ctx, const char* name, int value);
 

@@ -2,9 +2,12 @@
 // target only: 64-lane wavefronts, per-wave LDS traversal stacks, ballot/popcount queue compaction.
 //
 // Replaces, in the reference (paths relative to its root):
+//   k_cover         (none: what the driver's traversal does implicitly) which screen tiles can a mesh project onto
+//   k_entry         (none) per tile of a view — the camera; optionally a cube around the light — the deep subtrees its rays can hit
 //   k_raygen        src/shader.rgen:57-79     jitter hash + primary ray
 //   k_trace<...>    traceRayEXT, src/shader.rgen:86-87 (closest hit) and :111-112 (any hit, flags 13);
-//                   the traversal itself is driver code in the reference
+//                   the traversal itself is driver code in the reference (k_packet: the same query, one wavefront per
+//                   64-ray chunk — an alternative kept for comparison, off by default)
 //   k_shade         src/shader.rchit:50-96, src/shader.rmiss:11, src/shader.rgen:90-177
 //   shadow epilogue src/shader_shadow.rmiss:6 + src/shader.rgen:114-129
 //   k_resolve       src/shader.rgen:64,180-185
@@ -696,7 +699,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
       F3 qs, qb; uint3 rot;
       quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
-      const bool far = quant_far(qs, qb);   // a camera hundreds of TLAS extents from the scene: the TLAS does not cull (see quant_far)
+      const bool far = f.far_possible != 0 && quant_far(qs, qb);   // a camera hundreds of TLAS extents from the scene: the TLAS does not cull (see quant_far)
       // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
       const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
       const uint4 Q0 = rp[0], Q1 = rp[1];
@@ -815,7 +818,10 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 #define PH_END(k)
 #endif
 
-template <int MODE, bool ANY, bool COUNT, bool WIDE, bool ENTRY = false>
+// FAR: the kernel carries the far-ray logic (quant_far).  The host launches the FAR = false instantiations whenever no ray of the
+// launch can be far — camera, scene extent and instance scales decide that per frame (rt_api far_possible) — so the headline pays
+// nothing for it; the record-level entry point (arbitrary origins) and k_tail always carry it.
+template <int MODE, bool ANY, bool COUNT, bool WIDE, bool ENTRY = false, bool FAR = true>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
@@ -960,7 +966,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
       co = xform_point(m, wo); cd = xform_vec(m, wd);
       const float qlo3[3] = {ql.x, ql.y, ql.z}, qsc3[3] = {qsc.x, qsc.y, qsc.z};
-      quant_space(co, cd, qlo3, qsc3, qs, qb, rot); far = quant_far_o(co, qlo3, qsc3);
+      quant_space(co, cd, qlo3, qsc3, qs, qb, rot); far = FAR && quant_far_o(co, qlo3, qsc3);
     }
   };
 
@@ -999,7 +1005,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             }
             const uint32_t hdr = (uint32_t)r0.x;
             if (ent == ENTRY_FROM_ROOT) {
-              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
+              quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
               sp = 1; cur = a.sc.tlas_root;
             } else if (hdr == ENTRY_EMPTY) {
               sp = 1; cur = REF_DONE;   // nothing a ray of this tile can hit: the ray is finished (a miss)
@@ -1020,10 +1026,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
               cur = cur_new;
               __builtin_amdgcn_sched_barrier(0);   // the record's words are on the stack before the instance record is fetched (register peak of the kernel)
               if (ia != ENTRY_NO_INST) { int root; uint32_t imask; to_instance((int)ia, root, imask); cur_inst = (int)ia; }   // (k_entry never names an invisible instance)
-              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
+              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
             }
           } else {
-            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
+            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
             sp = 1;
             cur = a.sc.tlas_root;   // TLAS root (always interior)
           }
@@ -1211,7 +1217,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       // an interior TLAS node (a TLAS leaf sets up its own space, and the bottom sentinel ends the ray)
       cur_inst = -1;
       pop();
-      if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(wo, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }
+      if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(wo, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }
     }
     PH_END(2)
     PH_BEGIN(3)
@@ -1222,7 +1228,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       to_instance(ii, root, imask);
       if ((imask & 0xFFu) == 0u) {
         pop();   // invisible to the ray mask 0xFF; the ray space may still be that of the instance left before
-        if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = quant_far_o(wo, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }
+        if (cur >= 0) { quant_space(wo, wd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(wo, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }
       } else {
         push(REF_MARK);
         cur_inst = ii; cur = root;
@@ -1275,10 +1281,10 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
 // (five 256-thread workgroups per CU = five waves per SIMD is what the LDS admits: the register allocator of the shipped kernels
 // is held to that; the instrumented ones (k_trace_count) may take more registers rather than spill — a spill reload would
 // distort the very phase timings they exist to measure)
-template <int MODE, bool ANY, bool WIDE, bool ENTRY = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU))) void k_trace(TraceArgs a) { trace_body<MODE, ANY, false, WIDE, ENTRY>(a); }
-template <int MODE, bool ANY, bool WIDE, bool ENTRY = false>
-__global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY>(a); }
+template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU))) void k_trace(TraceArgs a) { trace_body<MODE, ANY, false, WIDE, ENTRY, FAR>(a); }
+template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true>
+__global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY, FAR>(a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_packet: PACKET traversal — one wavefront walks one 64-ray chunk TOGETHER.  The rays of a chunk are coherent by
@@ -2127,7 +2133,8 @@ static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& 
   const dim3 g(cfg.trace_blocks), b(256);
   if (cfg.variant == 0) {
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, false>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE, ANY, false>), g, b, 0, s, a);
+    else if (cfg.far || MODE == MODE_RAW) hipLaunchKernelGGL((k_trace<MODE, ANY, false, false, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE, ANY, false, false, false>), g, b, 0, s, a);
   } else if (cfg.variant == 2) {
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace<MODE, ANY, true>), g, b, 0, s, a);
@@ -2161,7 +2168,8 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.trace_blocks), b(256);
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true>), g, b, 0, s, a);
+    else if (cfg.far) hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false>), g, b, 0, s, a);
     return;
   }
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
@@ -2199,7 +2207,8 @@ void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, c
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.trace_blocks), b(256);
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE_SHADOW, true, false, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE_SHADOW, true, false, true>), g, b, 0, s, a);
+    else if (cfg.far) hipLaunchKernelGGL((k_trace<MODE_SHADOW, true, false, true, true>), g, b, 0, s, a);
+    else hipLaunchKernelGGL((k_trace<MODE_SHADOW, true, false, true, false>), g, b, 0, s, a);
     return;
   }
   launch_trace<MODE_SHADOW, true>(a, counting, cfg, s);

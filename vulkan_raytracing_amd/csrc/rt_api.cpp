@@ -168,6 +168,7 @@ struct rt_ctx {
   int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
   int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
   bool tail_full_grid = false;
+  int entry_max_instances = 8;   // "entry_max_instances": scenes with more instances walk from the TLAS root
   int entry_points = 1;          // 1: k_entry gives every covered tile a list of deep subtrees and its primary rays start there (result-identical)
   int shadow_entry = 0;          // 1: ... and every tile of a cube around the light one for the shadow rays (needs entry_points).  Off by default:
                                  // measured, it takes a third off the node visits of the shadow rays and nothing off the time of their kernel, while
@@ -543,6 +544,41 @@ SceneDev scene_dev(const rt_ctx* c) {
 
 int collect_stats(rt_ctx* c);
 
+// Can a ray of a frame be FAR (kernels.hip quant_far: |q_lo - origin| / q_scale beyond ~2e6 quanta on some axis) from a tree it
+// walks?  Origins are the camera (primary rays) and points of the scene itself (bounce and shadow rays start on surfaces: inside
+// the TLAS bounds).  World space: against the TLAS quantisation; object space of every instance: the same points through w2o
+// against the mesh's quantisation.  Conservative by a factor of four; false for every BASELINE workload, so their frames run the
+// kernels without the far-ray logic.
+bool far_possible(const rt_ctx* c, const UniformsDev& u) {
+  const Scene* S = c->scene;
+  const double K = 0.25 * 2097152.0;
+  double lo[3], hi[3];
+  for (int k = 0; k < 3; k++) {
+    // the TLAS bounds as its quantisation spans them (current after every build and refit), with the camera
+    const double tlo = c->tlas_q_lo[k], thi = (double)c->tlas_q_lo[k] + 65535.0 * (double)c->tlas_q_scale[k];
+    lo[k] = std::min(tlo, (double)u.position[k]); hi[k] = std::max(thi, (double)u.position[k]);
+    if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) return true;
+  }
+  double smin = std::min({(double)c->tlas_q_scale[0], (double)c->tlas_q_scale[1], (double)c->tlas_q_scale[2]});
+  for (int k = 0; k < 3; k++)
+    if (std::max(std::fabs(c->tlas_q_lo[k] - lo[k]), std::fabs(c->tlas_q_lo[k] - hi[k])) > K * smin) return true;
+  for (const rt_instance& in : c->h_inst) {
+    const Mesh& m = S->meshes[in.mesh];
+    if (!m.range.prim_count) continue;
+    float w2o[12];
+    invert_affine(in.transform, w2o);
+    smin = std::min({(double)m.q_scale[0], (double)m.q_scale[1], (double)m.q_scale[2]});
+    for (int cx = 0; cx < 8; cx++) {
+      const double p[3] = {(cx & 1) ? hi[0] : lo[0], (cx & 2) ? hi[1] : lo[1], (cx & 4) ? hi[2] : lo[2]};
+      for (int r = 0; r < 3; r++) {
+        const double v = w2o[4 * r] * p[0] + w2o[4 * r + 1] * p[1] + w2o[4 * r + 2] * p[2] + w2o[4 * r + 3];
+        if (!(std::fabs(m.q_lo[r] - v) <= K * smin)) return true;
+      }
+    }
+  }
+  return false;
+}
+
 // Calls that rewrite what a pending frame reads wait for that frame first (the reference waits on the frame's fence
 // before it touches the TLAS or the uniform buffer again, src/main.cpp:772-778).
 int quiesce(rt_ctx* c) {
@@ -691,7 +727,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     }
   }
   // Entry lists (k_entry) ride on the coverage mask: same tiles, same camera basis; the one-lane BVH2 kernel only.
-  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && (uint32_t)sc.n_inst < ENTRY_NO_INST;
+  // (a record opens ONE instance's BLAS; where the beam of a tile meets many instances — cfg5's ring of 16 — the TLAS phase of k_entry costs
+  // more than the records save: measured 1.86 vs 1.80 ms per frame, profiles/r03_experiments.txt — so records are for scenes of few instances)
+  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && sc.n_inst <= c->entry_max_instances;
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
   const bool light_on = entry_on && c->shadow_entry && std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2]);
   const int LT = c->light_tiles;
@@ -762,6 +800,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       cv.n = ENTRY_VIEWS; ev.n = ENTRY_VIEWS;
     }
   }
+  // far-ray logic in this frame's kernels only if some ray can be far (a re-render decides again from the same inputs)
+  LaunchCfg cfg = c->cfg;
+  cfg.far = (again != nullptr || far_possible(c, u)) ? 1 : 0;   // (a re-render does not trust the context's current instance list: it carries the logic)
+  f.far_possible = cfg.far;
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
   if (!c->timing || c->timed_frames >= 64) { c->ev_used = 0; c->spans.clear(); c->timed_frames = 0; }
@@ -800,7 +842,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         // mostly waits (1/8 shard with 16 slots in flight: 0.100 ms with 64 workgroups, 0.091 with 8, 0.088 with 2)
         // (contexts created since — other scenes on this GPU included — shrink every slot's share of the resident workgroups)
         int tb = std::min(c->tail_blocks, tail_grid(c->n_cu, c->tail_resident_per_cu, live_slots_on(c->device)));
-        if (tb <= 0) { { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); } { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); } continue; }
+        if (tb <= 0) { { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cfg, s); } { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); } continue; }
         const uint32_t expect = ((volatile uint32_t*)c->h_hint)[b];
         // (a lone slot keeps the full grid: nobody else needs the room and 64 workgroups finish 2 k rays in 43 us, 9 in 55)
         if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !c->tail_full_grid && c->scene->members.size() >= 3) {
@@ -809,11 +851,11 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
           if (lo >= N_SHARDS) want = (want + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
           tb = (int)std::min<long>(tb, std::max<long>(lo, want));
         }
-        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, c->cfg, tb, s);
+        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, cfg, tb, s);
         break;
       }
-      { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, c->cfg, s); }
-      { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, c->cfg, s); }
+      { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cfg, s); }
+      { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
         uint32_t tails[N_SHARDS * CNT_STRIDE];
@@ -824,7 +866,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         if (live == 0) break;
       }
     }
-    { Span sp(c, CAT_SHADOW, s); launch_trace_shadow(sc, f, c->counting, c->cfg, s); }
+    { Span sp(c, CAT_SHADOW, s); launch_trace_shadow(sc, f, c->counting, cfg, s); }
     { Span sp(c, CAT_RESOLVE, s); launch_resolve(f, u, s); }
   }
   HIP_TRY(c, hipGetLastError());
@@ -918,7 +960,7 @@ int collect_stats(rt_ctx* c) {
 // ================================================================================================
 extern "C" {
 
-int rt_abi_version(void) { return 4; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials
+int rt_abi_version(void) { return 5; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials; 5: rt_stats::frames_rerendered, entry records, BGRA8
 
 // Persistent traversal grid, workgroups per CU.  A lone context renders one frame at a time: the kernels are latency-bound and
 // 5 workgroups per CU (all the LDS admits) are fastest (cfg3: 1.00 ms vs 1.03 at 4, 1.28 at 2).  With several frame slots the
@@ -976,7 +1018,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1302,6 +1344,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "packet_trace") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2"); c->cfg.packet = value; return RT_OK; }
   if (k == "packet_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_blocks_per_cu must be 1..16"); c->cfg.packet_blocks = c->n_cu * value; return RT_OK; }
   if (k == "shadow_entry") { c->shadow_entry = value != 0; return RT_OK; }
+  if (k == "entry_max_instances") { if (value < 1 || value >= (int)ENTRY_NO_INST) return fail(c, RT_ERR_INVALID_ARGUMENT, "entry_max_instances out of range"); c->entry_max_instances = value; return RT_OK; }
   if (k == "light_tiles") {
     if (value < 8 || value > 512) return fail(c, RT_ERR_INVALID_ARGUMENT, "light_tiles must be 8..512");
     { int q = quiesce(c); if (q) return q; }

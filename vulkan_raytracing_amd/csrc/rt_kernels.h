@@ -66,6 +66,7 @@ struct FrameDev {
   const EntryRec* light_entry;
   uint32_t* sh_e;              // shadow queue: record index | ENTRY_REVERSE, or ENTRY_FROM_ROOT
   int light_tiles;
+  int far_possible;            // LaunchCfg::far of this frame (k_raygen's TLAS test)
 };
 
 // camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
@@ -105,6 +106,7 @@ struct LaunchCfg {
   int rays_per_lane;           // device-side grid sizing of the traversal kernels (see k_trace)
   int min_blocks;
   int variant;                 // 0: BVH2, one lane per ray; 1: BVH4, four lanes per ray; 2: 4-ary records, one lane per ray
+  int far;                     // 1: a ray of this frame may be FAR from a tree it walks (kernels.hip quant_far): launch the kernels that carry the far-ray logic
   int packet;                  // variant 0 only.  1: the primary rays (bounce 0) and the shadow rays are walked by k_packet, one wavefront per
                                // 64-ray chunk; 2: the record-level entry (rt_intersect) too (tests: incoherent rays through the packet kernel)
   int packet_blocks;           // persistent grid of k_packet (no LDS, few registers: eight workgroups per CU fit)
