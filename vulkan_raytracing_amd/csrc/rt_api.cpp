@@ -547,11 +547,11 @@ int collect_stats(rt_ctx* c);
 // Can a ray of a frame be FAR (kernels.hip quant_far: |q_lo - origin| / q_scale beyond ~2e6 quanta on some axis) from a tree it
 // walks?  Origins are the camera (primary rays) and points of the scene itself (bounce and shadow rays start on surfaces: inside
 // the TLAS bounds).  World space: against the TLAS quantisation; object space of every instance: the same points through w2o
-// against the mesh's quantisation.  Conservative by a factor of four; false for every BASELINE workload, so their frames run the
-// kernels without the far-ray logic.
+// against the mesh's quantisation — the device's own test (quant_far_o) evaluated at the corners of the box that holds every
+// possible origin.  False for every BASELINE workload, so their frames run the kernels without the far-ray logic.
 bool far_possible(const rt_ctx* c, const UniformsDev& u) {
   const Scene* S = c->scene;
-  const double K = 0.25 * 2097152.0;
+  const double K = 0.99 * 2097152.0;
   double lo[3], hi[3];
   for (int k = 0; k < 3; k++) {
     // the TLAS bounds as its quantisation spans them (current after every build and refit), with the camera
