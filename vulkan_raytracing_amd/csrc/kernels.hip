@@ -322,6 +322,18 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
   return mk3(div255(__builtin_fmaf(rb, wv, ra * iv)), div255(__builtin_fmaf(gb, wv, ga * iv)), div255(__builtin_fmaf(bb, wv, ba * iv)));
 }
 
+// src/shader.rgen:185 imageStore: the pixel in the frame's format — RGBA32F (the shader's declared rgba32f), or the 8-bit view the
+// reference's storage image really has (src/main.cpp:1899): clamp to [0,1], scale, round; R8G8B8A8 or the byte order of a B8G8R8A8 surface
+__device__ __forceinline__ void store_pixel(const FrameDev& f, uint32_t p, float4 px) {
+  if (f.out_rgba8) {
+    auto q = [](float v) -> unsigned char { v = fminf(fmaxf(v, 0.0f), 1.0f); return (unsigned char)(v * 255.0f + 0.5f); };
+    reinterpret_cast<uchar4*>(f.out)[p] = f.out_rgba8 == 2 ? make_uchar4(q(px.z), q(px.y), q(px.x), q(px.w)) : make_uchar4(q(px.x), q(px.y), q(px.z), q(px.w));
+  } else {
+    f.out[p] = px;
+  }
+}
+constexpr float PIXEL_DONE = 2.0f;   // alpha of sample 0's colour slot when k_raygen has already resolved the pixel (all its samples missed)
+
 // ------------------------------------------------------------------------------------------------
 // k_raygen: one thread per (8x8 pixel tile, sample, lane).  src/shader.rgen:62-79, fused with the
 // first step every traceRayEXT performs: the ray is tested against the boxes of the TLAS root.  A
@@ -679,6 +691,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   bool survive = false;
   F3 d = mk3(0.f, 0.f, 1.f);
   uint32_t sid = 0;
+  float4 miss_col = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     uint32_t y = ly;   // local row -> frame row of this shard's interleaved bands
     if (f.n_shards != 1) {
@@ -720,9 +733,21 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
     }
     if (!survive) {
       const F3 c = sample_sky(sc, mk3(d.x, d.y, -d.z));
-      f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
+      miss_col = make_float4(c.x, c.y, c.z, 1.0f);
     }
   }
+  // A pixel ALL of whose samples are misses is resolved right here (src/shader.rgen:180-185: the same ordered sum and division as
+  // k_resolve) when the workgroup holds all of them (spp <= 4): 4/5 of the headline's pixels are sky, and for them the per-sample
+  // colours never travel to HBM and back — one pixel and one marker are stored instead of four colours, k_resolve reads the marker only.
+  const bool missed = live && !survive;
+  const bool fuse = gridDim.z == 1u;
+  __shared__ float4 s_col[4][64];
+  __shared__ unsigned long long s_miss[4];
+  if (fuse) {
+    s_col[threadIdx.y][lane] = miss_col;
+    const uint64_t mm = __ballot(missed);
+    if (lane == 0) s_miss[threadIdx.y] = mm;
+  } else if (missed) f.sample_color[sid] = miss_col;
   // workgroups are handed to the XCDs round-robin in linear order
   const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & (N_SHARDS - 1);
   // ONE allocation per workgroup: the survivors of a tile's (up to four) samples form one run of the queue, so the 64-ray chunks
@@ -738,6 +763,20 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   }
   __syncthreads();
   const uint32_t slot = s_run[4] + s_run[threadIdx.y] + prefix_rank(smask);
+  if (fuse) {   // (s_col / s_miss were written before the first barrier above)
+    bool all = true;
+    for (uint32_t w = 0; w < blockDim.y; w++) all = all && ((s_miss[w] >> lane) & 1ull) != 0ull;
+    if (all) {
+      if (threadIdx.y == 0) {
+        float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
+        for (uint32_t w = 0; w < blockDim.y; w++) { const float4 c = s_col[w][lane]; r += c.x; g += c.y; b += c.z; al += c.w; }
+        const float nn = (float)spp;
+        const uint32_t p = ly * (uint32_t)f.width + x;     // = the sample id of sample 0
+        store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
+        f.sample_color[p] = make_float4(0.f, 0.f, 0.f, PIXEL_DONE);
+      }
+    } else if (missed) f.sample_color[sid] = miss_col;
+  }
   if (survive) {
     const uint32_t v = shard * f.shard_cap + slot;
     // (with entry lists the ray carries its tile instead of tmax, which is the constant 10000 of src/shader.rgen:87)
@@ -2027,22 +2066,14 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
 __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
   const uint32_t npx = (uint32_t)(f.rows * f.width);
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < npx) {
+  if (p < npx && f.sample_color[p].w != PIXEL_DONE) {   // (PIXEL_DONE: every sample of the pixel was a miss and k_raygen stored the pixel)
     float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
     for (uint32_t i = 0; i < u.samples_per_pixel; i++) {
       const float4 c = f.sample_color[(size_t)i * npx + p];
       r += c.x; g += c.y; b += c.z; al += c.w;
     }
     const float nn = (float)u.samples_per_pixel;
-    const float4 px = make_float4(r / nn, g / nn, b / nn, al / nn);
-    if (f.out_rgba8) {
-      // the reference's storage image really has the 8-bit surface format (src/main.cpp:1899): clamp to [0,1], scale, round
-      auto q = [](float v) -> unsigned char { v = fminf(fmaxf(v, 0.0f), 1.0f); return (unsigned char)(v * 255.0f + 0.5f); };
-      // byte order of the surface: R8G8B8A8, or B8G8R8A8 — what surfaceFormatList[0] usually is (src/main.cpp:1204)
-      reinterpret_cast<uchar4*>(f.out)[p] = f.out_rgba8 == 2 ? make_uchar4(q(px.z), q(px.y), q(px.x), q(px.w)) : make_uchar4(q(px.x), q(px.y), q(px.z), q(px.w));
-    } else {
-      f.out[p] = px;
-    }
+    store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
   }
   // The next frame of this context finds its counters zeroed (no memset dispatch per frame): it uses the other block.
   if (f.counters_next)

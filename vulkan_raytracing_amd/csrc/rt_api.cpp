@@ -133,6 +133,7 @@ struct rt_ctx {
   bool ev_frame_valid[2] = {false, false};
   float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
   uint32_t ovf_stride = STACK_OVF, ovf_alloc_stride = 0;
+  int stack_need = 0;            // deepest traversal stack of this slot's trees (k_packet keeps its wave stack in two VGPRs: 128 entries)
   int ovf_alloc_blocks = 0;
   // per-frame TLAS update without a host stall: records are assembled in pinned memory and copied on the context's stream;
   // a frame on another stream waits for ev_upload on the device
@@ -802,6 +803,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   }
   // far-ray logic in this frame's kernels only if some ray can be far (a re-render decides again from the same inputs)
   LaunchCfg cfg = c->cfg;
+  if (c->stack_need > 120) cfg.packet = 0;   // deeper than k_packet's 128-entry wave stack (a degenerate LBVH): the one-lane kernels spill to HBM instead
   cfg.far = (again != nullptr || far_possible(c, u)) ? 1 : 0;   // (a re-render does not trust the context's current instance list: it carries the logic)
   f.far_possible = cfg.far;
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
@@ -1196,6 +1198,7 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     const int tl = c->tlas.depth + 1;
     const int need2 = 2 + tl + blas_levels, needw = 2 + 3 * ((tl + 1) / 2) + 3 * ((blas_levels + 1) / 2);
     c->ovf_stride = (uint32_t)std::max<int>(STACK_OVF, (std::max(need2, needw) + 7) & ~7);
+    c->stack_need = need2 + ENTRY_WORDS + 2;   // (+ what an entry record puts on the stack before the walk starts)
   }
   if (1 + c->tlas4.stack_need + 1 + blas_need > STACK4_LDS)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "acceleration structure needs " + std::to_string(2 + c->tlas4.stack_need + blas_need) +
@@ -1597,7 +1600,9 @@ int rt_intersect(rt_ctx* c, size_t n, const float* rays8, int any_hit, rt_hit* o
   HIP_TRY(c, hipMemcpyAsync(c->d_counters + cnt_tail(0, 0), &n32, sizeof(n32), hipMemcpyHostToDevice, c->stream));
   HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
   hipEventRecord(e0, c->stream);
-  launch_trace_raw(scene_dev(c), d_o, d_d, d_h, n32, c->d_ovf, c->d_counters, any_hit != 0, counting != 0, c->cfg, c->stream);
+  LaunchCfg raw_cfg = c->cfg;
+  if (c->stack_need > 120) raw_cfg.packet = 0;   // (see enqueue_frame)
+  launch_trace_raw(scene_dev(c), d_o, d_d, d_h, n32, c->d_ovf, c->d_counters, any_hit != 0, counting != 0, raw_cfg, c->stream);
   hipEventRecord(e1, c->stream);
   HIP_TRY(c, hipStreamSynchronize(c->stream));
   HIP_TRY(c, hipGetLastError());
