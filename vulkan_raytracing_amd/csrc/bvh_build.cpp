@@ -5,9 +5,13 @@
 #include "bvh_build.h"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace rt {
 namespace {
@@ -40,70 +44,179 @@ inline int levels_needed(uint32_t n, int max_leaf) {
   return l;
 }
 
+// One node of the top-down build: bounds, the best binned-SAH split over the three axes (all three binned in one pass over the
+// references), the partition.  Nodes of at least PAR_MIN references do each of those passes on `threads` threads (chunked; the
+// partition is a stable two-pass scatter through `tmp`), smaller subtrees are whole tasks for the same threads.  The tree depends
+// only on the SETS of references on either side of every split — bin boxes and counts are order-independent — so it is the same
+// for every thread count; node numbers in `topo` are not (they are allocated from an atomic counter), and nothing reads them:
+// the emitter walks the links depth-first.
 struct Builder {
-  std::vector<Ref> refs;
+  std::vector<Ref> refs, tmp;
   int max_leaf, max_depth;
   float trav_cost = 1.0f;   // SAH: cost of visiting an interior node relative to one triangle test
   BuiltBvh* out;
+  int threads = 1;
+  // Node numbers, leaf count and depth are kept per task (one cache line hammered by every thread at every node made eight
+  // threads slower than one): a subtree over c references owns the next 2c - 2 node numbers below its root, reserved in one step.
+  struct Local { int next = 0; uint32_t leaves = 0; int depth = 0; };
+  std::atomic<int> next_node{0};
+  static constexpr uint32_t PAR_MIN = 16384;
+  static constexpr uint32_t SWEEP_MAX = 12;   // nodes of at most this many references take the exact sweep
 
-  int build(uint32_t first, uint32_t count, int depth) {
-    int me = (int)out->topo.size();
-    out->topo.push_back(BuildNode{});
-    out->depth = std::max(out->depth, depth);
-    Aabb bounds, cb;
-    box_reset(bounds); box_reset(cb);
-    for (uint32_t i = first; i < first + count; i++) {
-      box_grow(bounds, refs[i].box);
-      for (int k = 0; k < 3; k++) { cb.lo[k] = std::min(cb.lo[k], refs[i].c[k]); cb.hi[k] = std::max(cb.hi[k], refs[i].c[k]); }
+  struct Bins {
+    uint32_t cnt[3][NBINS];
+    Aabb bb[3][NBINS];
+    void reset() { for (int a = 0; a < 3; a++) for (int b = 0; b < NBINS; b++) { cnt[a][b] = 0; box_reset(bb[a][b]); } }
+  };
+  struct Task { int node; uint32_t first, count; int depth; };
+
+  template <class F>
+  void chunks(uint32_t first, uint32_t count, int nt, F&& f) {   // f(chunk index, chunk first, chunk count)
+    if (nt <= 1) { f(0, first, count); return; }
+    std::vector<std::thread> th;
+    const uint32_t per = (count + (uint32_t)nt - 1) / (uint32_t)nt;
+    for (int t = 1; t < nt; t++) {
+      const uint32_t b = std::min(count, per * (uint32_t)t), e = std::min(count, per * (uint32_t)(t + 1));
+      th.emplace_back([&f, t, first, b, e]() { f(t, first + b, e - b); });
     }
-    out->topo[me].box = bounds;
-    out->topo[me].first = first;
-    if (count <= 1) { out->topo[me].count = count; out->leaves++; return me; }
+    f(0, first, std::min(count, per));
+    for (auto& x : th) x.join();
+  }
 
-    // ---- best SAH split over 3 axes, NBINS bins each
-    float best_cost = BIG; int best_axis = -1, best_bin = -1;
-    for (int axis = 0; axis < 3; axis++) {
-      float ext = cb.hi[axis] - cb.lo[axis];
-      if (!(ext > 0.f)) continue;
-      uint32_t cnt[NBINS] = {0};
-      Aabb bb[NBINS];
-      for (int b = 0; b < NBINS; b++) box_reset(bb[b]);
-      float scale = (float)NBINS / ext;
+  // splits node `me`; returns false for a leaf, else the two children (node, first, count)
+  bool split(int me, uint32_t first, uint32_t count, int depth, int nt, Local& lc, Task& L, Task& R) {
+    lc.depth = std::max(lc.depth, depth);
+    if (count < PAR_MIN) nt = 1;
+    Aabb bounds, cb;
+    if (nt == 1) {
+      box_reset(bounds); box_reset(cb);
       for (uint32_t i = first; i < first + count; i++) {
-        int b = (int)((refs[i].c[axis] - cb.lo[axis]) * scale);
-        b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
-        cnt[b]++; box_grow(bb[b], refs[i].box);
+        box_grow(bounds, refs[i].box);
+        for (int k = 0; k < 3; k++) { cb.lo[k] = std::min(cb.lo[k], refs[i].c[k]); cb.hi[k] = std::max(cb.hi[k], refs[i].c[k]); }
       }
-      float la[NBINS]; uint32_t lc[NBINS];
-      Aabb acc; box_reset(acc); uint32_t c = 0;
-      for (int b = 0; b < NBINS; b++) { c += cnt[b]; box_grow(acc, bb[b]); la[b] = half_area(acc); lc[b] = c; }
-      box_reset(acc); c = 0;
-      for (int b = NBINS - 1; b >= 1; b--) {
-        c += cnt[b]; box_grow(acc, bb[b]);
-        uint32_t nl = lc[b - 1], nr = c;
-        if (nl == 0 || nr == 0) continue;
-        float cost = la[b - 1] * (float)nl + half_area(acc) * (float)nr;
-        if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b - 1; }
+    } else {
+      std::vector<Aabb> pb((size_t)nt), pc((size_t)nt);
+      chunks(first, count, nt, [&](int t, uint32_t f, uint32_t n) {
+        Aabb b, c; box_reset(b); box_reset(c);
+        for (uint32_t i = f; i < f + n; i++) {
+          box_grow(b, refs[i].box);
+          for (int k = 0; k < 3; k++) { c.lo[k] = std::min(c.lo[k], refs[i].c[k]); c.hi[k] = std::max(c.hi[k], refs[i].c[k]); }
+        }
+        pb[t] = b; pc[t] = c;
+      });
+      bounds = pb[0]; cb = pc[0];
+      for (int t = 1; t < nt; t++) { box_grow(bounds, pb[t]); box_grow(cb, pc[t]); }
+    }
+    BuildNode& node = out->topo[me];
+    node.box = bounds; node.first = first;
+    if (count <= 1) { node.count = count; lc.leaves++; return false; }
+
+    // ---- best SAH split over 3 axes: NBINS bins each, or — for the few references of the bottom levels, where a bin grid is
+    // mostly empty bins to reset and merge — every split position of the references sorted by centroid (the exact sweep)
+    float scale[3]; bool live[3];
+    for (int a = 0; a < 3; a++) { const float ext = cb.hi[a] - cb.lo[a]; live[a] = ext > 0.f; scale[a] = live[a] ? (float)NBINS / ext : 0.f; }
+    float best_cost = BIG; int best_axis = -1, best_bin = -1;
+    const bool sweep = count <= SWEEP_MAX;
+    uint8_t sweep_order[SWEEP_MAX];   // the references in the order of the best axis
+    if (sweep) {
+      for (int axis = 0; axis < 3; axis++) {
+        if (!live[axis]) continue;
+        uint8_t ord[SWEEP_MAX];
+        for (uint32_t i = 0; i < count; i++) {   // insertion sort by (centroid, id)
+          const Ref& r = refs[first + i];
+          uint32_t j = i;
+          while (j > 0) {
+            const Ref& q = refs[first + ord[j - 1]];
+            if (q.c[axis] < r.c[axis] || (q.c[axis] == r.c[axis] && q.id < r.id)) break;
+            ord[j] = ord[j - 1]; j--;
+          }
+          ord[j] = (uint8_t)i;
+        }
+        float ra[SWEEP_MAX];
+        Aabb acc; box_reset(acc);
+        for (uint32_t i = count; i-- > 1;) { box_grow(acc, refs[first + ord[i]].box); ra[i] = half_area(acc); }
+        box_reset(acc);
+        for (uint32_t k = 1; k < count; k++) {   // the first k references go left
+          box_grow(acc, refs[first + ord[k - 1]].box);
+          const float cost = half_area(acc) * (float)k + ra[k] * (float)(count - k);
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = (int)k; for (uint32_t i = 0; i < count; i++) sweep_order[i] = ord[i]; }
+        }
+      }
+    } else {
+      Bins stack_bins;
+      std::vector<Bins> heap_bins;
+      Bins* pbins = &stack_bins;
+      if (nt > 1) { heap_bins.resize((size_t)nt); pbins = heap_bins.data(); }
+      chunks(first, count, nt, [&](int t, uint32_t f, uint32_t n) {
+        Bins& B = pbins[t]; B.reset();
+        for (uint32_t i = f; i < f + n; i++)
+          for (int a = 0; a < 3; a++) {
+            if (!live[a]) continue;
+            int b = (int)((refs[i].c[a] - cb.lo[a]) * scale[a]);
+            b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
+            B.cnt[a][b]++; box_grow(B.bb[a][b], refs[i].box);
+          }
+      });
+      Bins& B = pbins[0];
+      for (int t = 1; t < nt; t++)
+        for (int a = 0; a < 3; a++) for (int b = 0; b < NBINS; b++) { B.cnt[a][b] += pbins[t].cnt[a][b]; box_grow(B.bb[a][b], pbins[t].bb[a][b]); }
+      for (int axis = 0; axis < 3; axis++) {
+        if (!live[axis]) continue;
+        float la[NBINS]; uint32_t lc[NBINS];
+        Aabb acc; box_reset(acc); uint32_t c = 0;
+        for (int b = 0; b < NBINS; b++) { c += B.cnt[axis][b]; box_grow(acc, B.bb[axis][b]); la[b] = half_area(acc); lc[b] = c; }
+        box_reset(acc); c = 0;
+        for (int b = NBINS - 1; b >= 1; b--) {
+          c += B.cnt[axis][b]; box_grow(acc, B.bb[axis][b]);
+          uint32_t nl = lc[b - 1], nr = c;
+          if (nl == 0 || nr == 0) continue;
+          float cost = la[b - 1] * (float)nl + half_area(acc) * (float)nr;
+          if (cost < best_cost) { best_cost = cost; best_axis = axis; best_bin = b - 1; }
+        }
       }
     }
     float pa = half_area(bounds);
     if (count <= (uint32_t)max_leaf) {
       float leaf_cost = pa * (float)count;
       float split_cost = best_axis >= 0 ? pa * trav_cost + best_cost : BIG;
-      if (leaf_cost <= split_cost) { out->topo[me].count = count; out->leaves++; return me; }
+      if (leaf_cost <= split_cost) { node.count = count; lc.leaves++; return false; }
     }
     uint32_t mid = first;
     bool ok = false;
     int budget = max_depth - depth - 1;  // levels available below each child
-    if (best_axis >= 0) {
-      float ext = cb.hi[best_axis] - cb.lo[best_axis];
-      float scale = (float)NBINS / ext; float lo = cb.lo[best_axis]; int ax = best_axis, bbin = best_bin;
-      auto it = std::partition(refs.begin() + first, refs.begin() + first + count, [&](const Ref& r) {
-        int b = (int)((r.c[ax] - lo) * scale);
+    if (best_axis >= 0 && sweep) {
+      Ref sorted[SWEEP_MAX];
+      for (uint32_t i = 0; i < count; i++) sorted[i] = refs[first + sweep_order[i]];
+      for (uint32_t i = 0; i < count; i++) refs[first + i] = sorted[i];
+      mid = first + (uint32_t)best_bin;
+      uint32_t nl = mid - first, nr = count - nl;
+      ok = levels_needed(nl, max_leaf) <= budget && levels_needed(nr, max_leaf) <= budget;
+    } else if (best_axis >= 0) {
+      const float sc = scale[best_axis], lo = cb.lo[best_axis]; const int ax = best_axis, bbin = best_bin;
+      auto left = [&](const Ref& r) {
+        int b = (int)((r.c[ax] - lo) * sc);
         b = b < 0 ? 0 : (b >= NBINS ? NBINS - 1 : b);
         return b <= bbin;
-      });
-      mid = (uint32_t)(it - refs.begin());
+      };
+      if (nt > 1) {   // stable scatter through tmp: lefts of all chunks, then rights of all chunks
+        std::vector<uint32_t> nl((size_t)nt + 1, 0), nr((size_t)nt + 1, 0);
+        chunks(first, count, nt, [&](int t, uint32_t f, uint32_t n) {
+          uint32_t l = 0;
+          for (uint32_t i = f; i < f + n; i++) l += left(refs[i]) ? 1u : 0u;
+          nl[(size_t)t + 1] = l; nr[(size_t)t + 1] = n - l;
+        });
+        for (int t = 0; t < nt; t++) { nl[(size_t)t + 1] += nl[t]; nr[(size_t)t + 1] += nr[t]; }
+        const uint32_t total_left = nl[nt];
+        chunks(first, count, nt, [&](int t, uint32_t f, uint32_t n) {
+          uint32_t l = first + nl[t], r = first + total_left + nr[t];
+          for (uint32_t i = f; i < f + n; i++) { if (left(refs[i])) tmp[l++] = refs[i]; else tmp[r++] = refs[i]; }
+        });
+        chunks(first, count, nt, [&](int, uint32_t f, uint32_t n) { std::copy(tmp.begin() + f, tmp.begin() + f + n, refs.begin() + f); });
+        mid = first + total_left;
+      } else {
+        auto it = std::partition(refs.begin() + first, refs.begin() + first + count, left);
+        mid = (uint32_t)(it - refs.begin());
+      }
       uint32_t nl = mid - first, nr = count - nl;
       ok = nl > 0 && nr > 0 && levels_needed(nl, max_leaf) <= budget && levels_needed(nr, max_leaf) <= budget;
     }
@@ -114,10 +227,52 @@ struct Builder {
       std::nth_element(refs.begin() + first, refs.begin() + mid, refs.begin() + first + count,
                        [ax](const Ref& a, const Ref& b) { return a.c[ax] < b.c[ax] || (a.c[ax] == b.c[ax] && a.id < b.id); });
     }
-    int l = build(first, mid - first, depth + 1);
-    int r = build(mid, first + count - mid, depth + 1);
-    out->topo[me].left = l; out->topo[me].right = r;
-    return me;
+    L = Task{lc.next++, first, mid - first, depth + 1};
+    R = Task{lc.next++, mid, first + count - mid, depth + 1};
+    node.left = L.node; node.right = R.node;
+    return true;
+  }
+
+  void subtree(const Task& t, Local& lc) {   // one thread, depth-first
+    Task L, R;
+    if (!split(t.node, t.first, t.count, t.depth, 1, lc, L, R)) return;
+    subtree(L, lc); subtree(R, lc);
+  }
+
+  void run(uint32_t n) {
+    out->topo.assign(2 * (size_t)n, BuildNode{});   // a binary tree over n references has at most 2n - 1 nodes
+    if (threads > 1) tmp.resize(n);
+    std::vector<Task> big, small;
+    Local top; top.next = 1;   // node 0 = the root
+    big.push_back(Task{0, 0, n, 0});
+    while (!big.empty()) {   // the large nodes one after the other, every pass over their references on all threads
+      const Task t = big.back(); big.pop_back();
+      if (threads <= 1 || t.count < PAR_MIN) { small.push_back(t); continue; }
+      Task L, R;
+      if (split(t.node, t.first, t.count, t.depth, threads, top, L, R)) { big.push_back(R); big.push_back(L); }
+    }
+    next_node = top.next;
+    // the rest: whole subtrees, largest first, handed out from an atomic cursor
+    std::sort(small.begin(), small.end(), [](const Task& a, const Task& b) { return a.count > b.count || (a.count == b.count && a.first < b.first); });
+    std::atomic<size_t> cursor{0};
+    const int nw = (int)std::max<size_t>(1, std::min<size_t>((size_t)threads, small.size()));
+    std::vector<Local> res((size_t)nw);
+    auto worker = [&](int w) {
+      Local acc;
+      for (size_t i; (i = cursor.fetch_add(1)) < small.size();) {
+        Local lc; lc.next = next_node.fetch_add(2 * (int)small[i].count - 2);   // (its root has a number already)
+        subtree(small[i], lc);
+        acc.leaves += lc.leaves; acc.depth = std::max(acc.depth, lc.depth);
+      }
+      res[(size_t)w] = acc;
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nw; t++) th.emplace_back(worker, t);
+    worker(0);
+    for (auto& x : th) x.join();
+    out->topo.resize((size_t)std::min<long long>(next_node.load(), 2 * (long long)n));
+    out->depth = top.depth; out->leaves = top.leaves;
+    for (const Local& r : res) { out->depth = std::max(out->depth, r.depth); out->leaves += r.leaves; }
   }
 };
 
@@ -156,6 +311,22 @@ struct Emitter {
 
 }  // namespace
 
+// Threads of the host builder: RT_BUILD_THREADS, else min(cores visible, the cgroup's CPU quota rounded up, 16).
+static int build_threads() {
+  if (const char* e = getenv("RT_BUILD_THREADS")) { const int v = atoi(e); if (v >= 1) return std::min(v, 64); }
+  int n = (int)std::thread::hardware_concurrency();
+  if (n < 1) n = 1;
+  if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+    long long quota = 0, period = 0; char word[32] = {0};
+    if (fscanf(f, "%31s %lld", word, &period) == 2 && strcmp(word, "max") != 0 && period > 0) {
+      quota = atoll(word);
+      if (quota > 0) n = std::min<int>(n, (int)((quota + period - 1) / period));
+    }
+    fclose(f);
+  }
+  return std::max(1, std::min(n, 16));
+}
+
 static void build_bvh_impl(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, bool direct_ids, BuiltBvh& out, float trav_cost = 1.0f) {
   out = BuiltBvh{};
   box_reset(out.bounds);
@@ -170,7 +341,12 @@ static void build_bvh_impl(const Aabb* prim_boxes, uint32_t n, int max_leaf, int
     for (int k = 0; k < 3; k++) b.refs[i].c[k] = 0.5f * prim_boxes[i].lo[k] + 0.5f * prim_boxes[i].hi[k];
     box_grow(out.bounds, prim_boxes[i]);
   }
-  if (n > 0) b.build(0, n, 0);
+  b.threads = n >= 2 * Builder::PAR_MIN ? build_threads() : 1;
+  const bool timing = getenv("RT_BUILD_TIMING") != nullptr;
+  auto now = []() { return std::chrono::steady_clock::now(); };
+  auto t_a = now();
+  if (n > 0) b.run(n);
+  auto t_b = now();
   out.order.resize(n);
   for (uint32_t i = 0; i < n; i++) out.order[i] = b.refs[i].id;
   out.emit_of.assign(out.topo.size(), -1);
@@ -186,6 +362,8 @@ static void build_bvh_impl(const Aabb* prim_boxes, uint32_t n, int max_leaf, int
   } else {
     em.emit(0);
   }
+  if (timing && n > 1000) fprintf(stderr, "[bvh_build] n %u threads %d: tree %.1f ms, emit %.1f ms\n", n, b.threads,
+                                  std::chrono::duration<double, std::milli>(t_b - t_a).count(), std::chrono::duration<double, std::milli>(now() - t_b).count());
 }
 
 void build_bvh(const Aabb* prim_boxes, uint32_t n, int max_leaf, int max_depth, BuiltBvh& out) {

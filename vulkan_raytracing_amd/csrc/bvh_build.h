@@ -1,6 +1,7 @@
 // bvh_build.h — host-side acceleration-structure builder (replaces the driver work behind
 // vkCmdBuildAccelerationStructuresKHR, reference src/main.cpp:495-498 (BLAS) and :730-733 (TLAS)).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 #include <vector>
 
