@@ -219,8 +219,9 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
  * 1..maxBounceCount in one launch when the previous frame had few secondary rays (default), 2 = always;
  * "output_rgba8" 1 = every entry point that returns a frame stores 8-bit RGBA (clamp to [0,1], x255, round; the format
  * the reference's storage image really has, src/main.cpp:1899) instead of RGBA32F — a quarter of the PCIe bytes;
- * "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device LBVH (default:
- * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357), 0 = host binned-SAH;
+ * "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device builder (default:
+ * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357 — a binned-SAH tree made level by
+ * level; the environment variable RT_GPU_BVH_ALGO = 1 / 2 selects the LBVH / PLOC builders instead), 0 = host binned-SAH (threaded);
  * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids; "primary_cover" 1 (default) = before ray generation the
  * frontier boxes of every instance's BLAS are projected onto 8x8-pixel screen tiles and the samples of tiles no mesh can
  * project onto are shaded as misses without any box test, 0 = every primary ray is tested against the TLAS;

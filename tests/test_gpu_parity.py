@@ -412,7 +412,7 @@ def test_headless_cpp_host_matches_python_path(tmp_path):
     assert np.abs(ppm - np.clip(img[..., :3], 0, 1)).max() <= 0.5 / 255 + 1e-6
 
 
-@pytest.mark.parametrize("algo", ["1", "2"])
+@pytest.mark.parametrize("algo", ["1", "2", "3"])
 def test_device_built_blas_gives_identical_results(ctx, algo, monkeypatch):
     """rt_build_blas with blas_builder = 1 builds the BLAS on the GPU (csrc/bvh_gpu.hip: LBVH = algo 1, the default, or
     PLOC = algo 2).  Any valid BVH yields the same hits, so records and images must equal those of the host SAH builder
@@ -559,7 +559,7 @@ def test_cfg4_size_properties(ctx):
     assert total == st.rays_primary + st.rays_secondary + st.rays_shadow
 
 
-@pytest.mark.parametrize("algo", ["1", "2"])
+@pytest.mark.parametrize("algo", ["1", "2", "3"])
 def test_device_builders_on_degenerate_soup(ctx, algo, monkeypatch, tmp_path):
     """Duplicate Morton codes, coincident and zero-area triangles, all triangles in one plane: the device builders must
     still produce a valid tree (checked against brute force through the oracle)."""

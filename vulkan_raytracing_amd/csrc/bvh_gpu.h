@@ -1,4 +1,4 @@
-// bvh_gpu.h — device-side BLAS builder (LBVH), see bvh_gpu.hip.
+// bvh_gpu.h — device-side BLAS builders (binned SAH level by level — the default —, LBVH, PLOC), see bvh_gpu.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 

@@ -187,7 +187,7 @@ struct rt_ctx {
   bool last_empty = false;       // the last enqueued frame had no rows (nothing was launched)
   uint32_t* h_hint = nullptr;    // pinned, device-visible array [CNT_MAX_BOUNCES]: bounce-queue sizes of the most recent finished
   uint32_t* d_hint = nullptr;    // frame (written by k_resolve; a speed hint only, never affects results)
-  int blas_builder = 1;          // 1: device LBVH (bvh_gpu.hip, default), 0: host binned-SAH
+  int blas_builder = 1;          // 1: device builder (bvh_gpu.hip: binned SAH level by level; RT_GPU_BVH_ALGO 1 / 2 = LBVH / PLOC), default; 0: host binned-SAH (threaded)
   int timing = 0;                // 0 off, 1 HIP events around every kernel, 2 around the closest-hit traversal launches only
   bool counting = false;
   std::vector<hipEvent_t> ev_pool;
@@ -329,8 +329,8 @@ int link_blas(rt_ctx* c) {
   }
   // Hot-node order: the kernels keep the first HOT_NODES entries of the node array in LDS, so the nodes every ray meets —
   // the top levels of every BLAS — are moved to the front: a breadth-first walk over all meshes at once (roots first, then
-  // their children, ...) names the first HOT_NODES interior nodes; everything below keeps its builder order (Morton order
-  // for the device LBVH: good cache locality in the lower levels).  Roots and links are rewritten; any valid numbering
+  // their children, ...) names the first HOT_NODES interior nodes; everything below keeps its builder order (level by level
+  // for the device SAH builder, Morton order for the LBVH).  Roots and links are rewritten; any valid numbering
   // gives the same hits.
   {
     std::vector<int32_t> hot;              // old indices in breadth-first order
@@ -1116,7 +1116,7 @@ int rt_build_blas(rt_ctx* c, int mesh) {
   Mesh& m = S->meshes[mesh];
   m.gpu_built = false;
   if (c->blas_builder == 1 && c->cfg.variant != 1 && m.range.prim_count >= 8) {
-    // device build: LBVH straight from the uploaded vertex/index buffers; the result is downloaded once so that the
+    // device build straight from the uploaded vertex/index buffers; the result is downloaded once so that the
     // linker treats every mesh alike
     HIP_TRY(c, hipSetDevice(c->device));
     GpuBlas g; std::string err;
@@ -1355,7 +1355,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
-  if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device LBVH)"); for (rt_ctx* m : c->scene->members) m->blas_builder = value; return RT_OK; }
+  if (k == "blas_builder") { if (value != 0 && value != 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "blas_builder must be 0 (host SAH) or 1 (device)"); for (rt_ctx* m : c->scene->members) m->blas_builder = value; return RT_OK; }
   if (k == "trace_rays_per_lane") { if (value < 1 || value > 64) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_rays_per_lane must be 1..64"); c->cfg.rays_per_lane = value; return RT_OK; }
   if (k == "trace_min_blocks") { if (value < 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_min_blocks must be >= 8"); c->cfg.min_blocks = value; return RT_OK; }
   if (k == "shade_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "shade_blocks_per_cu must be 1..16"); c->cfg.shade_blocks = c->n_cu * value; return RT_OK; }
