@@ -288,22 +288,67 @@ namespace {
 // (re)allocate the device arrays: BLAS part + MAX_SLOTS TLAS regions, and upload the BLAS part
 int alloc_scene_arrays(rt_ctx* c);
 
+// Cache-line layout of a mesh's quantized nodes: four 32-byte nodes share a 128-byte line of the vector L1, and the step a walk takes
+// most often is parent -> child.  Nodes are laid out in TREELETS of a node and its interior children (1-3 nodes, never split across a
+// line; lines are filled greedily, treelets in depth-first order, a treelet's grandchildren are the roots of the next ones), so every
+// second step of a descent stays inside the line the previous one fetched.  Unused slots repeat node 0 (never referenced, valid for
+// walkers that scan the array).  The root stays node 0; any numbering gives the same hits.
+static std::vector<BvhNodeQ> treelet_layout(const std::vector<BvhNodeQ>& in) {
+  if (in.size() < 4) return in;
+  std::vector<BvhNodeQ> out;
+  out.reserve(in.size() + in.size() / 2);
+  std::vector<int32_t> new_of(in.size(), -1);
+  std::vector<int32_t> todo;   // treelet roots, depth-first
+  todo.push_back(0);
+  while (!todo.empty()) {
+    const int32_t r = todo.back(); todo.pop_back();
+    const BvhNodeQ& q = in[r];
+    int32_t kids[2]; int nk = 0;
+    if (q.child0 >= 0) kids[nk++] = q.child0;
+    if (q.child1 >= 0 && q.child1 != q.child0) kids[nk++] = q.child1;
+    const size_t size = 1 + (size_t)nk;
+    if ((out.size() & 3u) + size > 4u) while (out.size() & 3u) out.push_back(in[0]);
+    new_of[r] = (int32_t)out.size(); out.push_back(q);
+    for (int k = 0; k < nk; k++) { new_of[kids[k]] = (int32_t)out.size(); out.push_back(in[kids[k]]); }
+    for (int k = nk - 1; k >= 0; k--) {   // the grandchildren start treelets of their own (first child's subtree first)
+      const BvhNodeQ& c = in[kids[k]];
+      if (c.child1 >= 0 && c.child1 != c.child0) todo.push_back(c.child1);
+      if (c.child0 >= 0) todo.push_back(c.child0);
+    }
+  }
+  for (BvhNodeQ& q : out) {
+    if (q.child0 >= 0) q.child0 = new_of[q.child0];
+    if (q.child1 >= 0) q.child1 = new_of[q.child1];
+  }
+  return out;
+}
+
 int link_blas(rt_ctx* c) {
   Scene* S = c->scene;
   size_t nn = 0, nt = 0, nn4 = 0;
-  for (auto& m : S->meshes) {
+  static const bool line_layout = [] { const char* e = getenv("RT_NODE_LAYOUT"); return e ? atoi(e) != 0 : true; }();
+  std::vector<std::vector<BvhNodeQ>> laid(S->meshes.size());   // what is linked: the mesh's nodes in their final order
+  std::vector<size_t> gap_from(S->meshes.size(), 0);
+  for (size_t mi = 0; mi < S->meshes.size(); mi++) {
+    Mesh& m = S->meshes[mi];
     if (!m.built) continue;
+    if (!m.gpu_built) quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
+    laid[mi] = line_layout ? treelet_layout(m.qnodes) : m.qnodes;
+    gap_from[mi] = nn;
+    nn = (nn + 3u) & ~(size_t)3u;   // every mesh starts on a line
     m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt; m.node_base4 = (int32_t)nn4;
-    nn += m.gpu_built ? m.qnodes.size() : m.bvh.nodes.size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
+    nn += laid[mi].size(); nt += m.tris.size(); nn4 += m.bvh4.nodes.size();
   }
   std::vector<BvhNodeQ> nodes(nn);
   std::vector<Bvh4Node> nodes4(nn4);
   std::vector<TriPacket> tris(nt);
-  for (auto& m : S->meshes) {
+  for (size_t mi = 0; mi < S->meshes.size(); mi++) {
+    Mesh& m = S->meshes[mi];
     if (!m.built) continue;
-    if (!m.gpu_built) quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
-    for (size_t i = 0; i < m.qnodes.size(); i++) {
-      BvhNodeQ n = m.qnodes[i];
+    const std::vector<BvhNodeQ>& mq = laid[mi];
+    for (size_t i = gap_from[mi]; i < (size_t)m.node_base; i++) nodes[i] = nodes[0];   // (alignment gap in front of this mesh: copies of a valid node)
+    for (size_t i = 0; i < mq.size(); i++) {
+      BvhNodeQ n = mq[i];
       auto fix = [&](int32_t ch) -> int32_t {
         if (ch >= 0) return ch + m.node_base;
         uint32_t ref = (uint32_t)(~ch);
@@ -324,7 +369,7 @@ int link_blas(rt_ctx* c) {
       nodes4[m.node_base4 + i] = n;
     }
     if (!m.tris.empty()) memcpy(&tris[m.tri_base], m.tris.data(), m.tris.size() * sizeof(TriPacket));
-    m.levels = bvh2_levels(m.qnodes.data(), m.qnodes.size(), 0);
+    m.levels = bvh2_levels(mq.data(), mq.size(), 0);
     if (m.levels < 0) return fail(c, RT_ERR_DEVICE, "BLAS builder produced a node graph that is not a tree");
   }
   // Hot-node order: the kernels keep the first HOT_NODES entries of the node array in LDS, so the nodes every ray meets —
