@@ -559,6 +559,41 @@ def test_cfg4_size_properties(ctx):
     assert total == st.rays_primary + st.rays_secondary + st.rays_shadow
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_tri", [8, 17, 33, 300])
+def test_device_sah_builder_on_small_and_coincident_meshes(n_tri, tmp_path):
+    """The level-by-level SAH builder (bvh_gpu.hip k_sah_*) at its seams: meshes around the 16-reference threshold between binned nodes
+    and swept nodes, and a mesh whose triangles all share ONE centroid (no axis separates them: binned nodes fall back to position
+    medians with the parent's box, swept nodes to halves) — hit records against the oracle's brute force."""
+    rng = np.random.default_rng(100 + n_tri)
+    for coincident in (False, True):
+        if coincident:
+            base = rng.normal(size=(3, 3))
+            tris = np.stack([base * s for s in np.linspace(-1.0, 1.0, n_tri) if True])   # scaled copies about the origin: every centroid = the scaled base centroid
+            tris = tris - tris.mean(axis=1, keepdims=True)                                 # ... moved to the origin: all centroids coincide
+        else:
+            tris = rng.normal(size=(n_tri, 3, 3))
+        p = tmp_path / ("m%d_%d.obj" % (n_tri, int(coincident)))
+        with open(p, "w") as f:
+            for t in tris:
+                for v in t:
+                    f.write("v %.6f %.6f %.6f\nvn 0 0 1\n" % tuple(v))
+            for i in range(len(tris)):
+                f.write("f %d//%d %d//%d %d//%d\n" % (3 * i + 1, 3 * i + 1, 3 * i + 2, 3 * i + 2, 3 * i + 3, 3 * i + 3))
+        c2 = RtContext(0)
+        try:
+            inst = [host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)]
+            u = host.default_uniforms(max_bounce_count=1, samples_per_pixel=1, center_object_type=0, orbiting_object_type=0)
+            sp = scenes.ScenePair([str(p)], inst, u, ctx=c2)
+            rays = scenes.random_rays(6000, seed=5, origin_radius=6.0, target_radius=1.5)
+            g, _ = c2.intersect(rays)
+            o = sp.orc.intersect(rays, use_bvh=False)
+            assert (o["inst"] >= 0).mean() > 0.05
+            assert np.array_equal(g, o), (n_tri, coincident)
+        finally:
+            c2.close()
+
+
 @pytest.mark.parametrize("algo", ["1", "2", "3"])
 def test_device_builders_on_degenerate_soup(ctx, algo, monkeypatch, tmp_path):
     """Duplicate Morton codes, coincident and zero-area triangles, all triangles in one plane: the device builders must

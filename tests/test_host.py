@@ -361,6 +361,24 @@ def test_host_bvh_builders_invariants(resources, tmp_path):
     assert st["leaves"] >= 2256 // 4 and st["nodes"] < 2256
 
 
+def test_threaded_host_builder_makes_the_same_tree(tmp_path, monkeypatch):
+    """csrc/bvh_build.cpp splits nodes of >= 16 384 references on all threads (chunked binning, stable two-pass partition) and hands the
+    subtrees below to the same threads as tasks.  Split decisions depend only on the SETS on either side of a split, so the tree must
+    not depend on the thread count: same node / leaf counts, depth and BVH4 collapse, no invariant violated, for 1, 3 and 8 threads."""
+    from vulkan_raytracing_amd import api
+    p = str(tmp_path / "s.obj")
+    assert host.hlib().rth_write_armadillo_standin(p.encode(), 64) == 0     # 81 920 triangles: the root and its first levels take the threaded path
+    g = host.SceneGeometry([p])
+    monkeypatch.setenv("RT_BVH_MAX_LEAF", "1")
+    seen = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("RT_BUILD_THREADS", threads)
+        rc, st = api.check_builders(g.verts, g.idx)
+        assert rc == 0 and st["violations"] == 0 and st["reached"] == 81920 and st["max_leaf"] == 1, (threads, st)
+        seen.append(st)
+    assert seen[0] == seen[1] == seen[2], seen
+
+
 def test_mtl_files_are_parsed(resources):
     """The loader reads the MTL files the reference ships (the renderer, like the reference's, then ignores them)."""
     import ctypes as C
