@@ -1155,6 +1155,40 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     // selects.  The visit is the unit of the kernel's dependent instruction chain, which is what bounds it.
     typedef __attribute__((address_space(3))) volatile int lds_vint;   // volatile AND still an LDS pointer (ds_read/ds_write)
     lds_vint* const stk_lds = (lds_vint*)stk;
+#ifdef RT_EXP_VISIT_STAMPS
+    // measurement build (instrumented kernels only; tools/visit_stamps.sh): what a wave's fast visit is made of — RT_EXP_VISIT_STAMPS 1: from
+    // the issue of the node fetch to its arrival (forced s_waitcnt), 2: from there to the end of the visit (box tests, selects, stack
+    // store), 3: the whole visit.  profiles/r03_visit_stamps.txt: 1 670 + 408 = 2 118 cycles (closest hit), 1 043 + 445 = 1 494 (shadow).
+    auto fast_step = [&]() {
+      const uint64_t vs_t0 = COUNT ? __builtin_readcyclecounter() : 0;
+      uint4 Q0 = make_uint4(0, 0, 0, 0), Q1 = Q0; int top = 0;
+      if (cur >= 0) {
+        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));
+        Q0 = np[0]; Q1 = np[1];
+        top = stk_lds[(sp - 1) * 64];
+      }
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      const uint64_t vs_t1 = COUNT ? __builtin_readcyclecounter() : 0;
+      if (cur >= 0) {
+        const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
+        if (COUNT) cnt_nodes++;
+        float t0, t1;
+        const bool h0 = slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t0);
+        const bool h1 = slab_q(Q0.w, Q1.x, Q1.y, qs, qb, rot, (MODE == MODE_RAW ? tmin_ray : a.tmin), best_t, t1);
+        const bool both = h0 && h1, none = !(h0 || h1), swap = t1 < t0;
+        const uint32_t pm = 0u - (uint32_t)both;
+        stk_lds[(((uint32_t)sp & pm) | ((uint32_t)STACK2_LDS & ~pm)) * 64u] = swap ? ch.x : ch.y;
+        const int one = h0 ? ch.x : ch.y;
+        cur = both ? (swap ? ch.y : ch.x) : (none ? top : one);
+        sp += (both ? 1 : 0) - (none ? 1 : 0);
+      }
+      if (COUNT) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const uint64_t vs_t2 = __builtin_readcyclecounter();
+        if (lane == 0) { diag_iters++; diag_busy += RT_EXP_VISIT_STAMPS == 1 ? vs_t1 - vs_t0 : RT_EXP_VISIT_STAMPS == 2 ? vs_t2 - vs_t1 : vs_t2 - vs_t0; }
+      }
+    };
+#else
     auto fast_step = [&]() {
       if (cur >= 0) {
         uint4 Q0, Q1;
@@ -1189,6 +1223,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         sp += (both ? 1 : 0) - (none ? 1 : 0);
       }
     };
+#endif
 #ifdef RT_EXP_PHASE_DIAG   // experiment: diag = (outer passes, cycles inside the interior loop, wave cycles)
     const uint64_t ph_t0 = COUNT ? __builtin_readcyclecounter() : 0;
 #endif
@@ -1196,7 +1231,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     for (;;) {
       const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(cur >= 0));
       if (n_int == 0 || n_int < keep_going) break;
-#if !defined(RT_EXP_PHASE_DIAG) && !defined(RT_EXP_DEEP_DIAG) && !defined(RT_EXP_PHASE_SEL)
+#if !defined(RT_EXP_PHASE_DIAG) && !defined(RT_EXP_DEEP_DIAG) && !defined(RT_EXP_PHASE_SEL) && !defined(RT_EXP_VISIT_STAMPS)
       if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
 #endif
       // fast visits need every stack they touch inside the LDS rows: sp - 1 >= 0 always holds for a live ray, and
