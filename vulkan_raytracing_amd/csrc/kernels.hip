@@ -127,6 +127,22 @@ __device__ __forceinline__ F3 ambient_of(const SceneDev& sc, uint32_t mat) {
 
 // ------------------------------------------------------------------------------------------------
 // wave-level helpers (wave64)
+// Streamed data — ray queues, hit records, per-sample colours: written once by one kernel, read once by the next — can carry the
+// non-temporal hint so that it does not push the acceleration structure out of the 4-MB L2 of its XCD (experiment: -DRT_NT_STREAMS).
+typedef float rt_v4f __attribute__((ext_vector_type(4)));
+#ifndef RT_NT_STREAMS
+#define RT_NT_STREAMS 1   /* bit 0: loads (default), bit 1: stores, bit 2: the cube-map taps */
+#endif
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+  if (RT_NT_STREAMS & 1) { const rt_v4f v = __builtin_nontemporal_load(reinterpret_cast<const rt_v4f*>(p)); return make_float4(v.x, v.y, v.z, v.w); }
+  return *p;
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+  if (RT_NT_STREAMS & 2) { rt_v4f w; w.x = v.x; w.y = v.y; w.z = v.z; w.w = v.w; __builtin_nontemporal_store(w, reinterpret_cast<rt_v4f*>(p)); }
+  else *p = v;
+}
+__device__ __forceinline__ int ld_stream(const int* p) { return (RT_NT_STREAMS & 1) ? __builtin_nontemporal_load(p) : *p; }
+__device__ __forceinline__ void st_stream(int* p, int v) { if (RT_NT_STREAMS & 2) __builtin_nontemporal_store(v, p); else *p = v; }
 __device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 __device__ __forceinline__ uint32_t prefix_rank(uint64_t mask) {  // # set bits below this lane
   return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -303,8 +319,12 @@ __device__ __forceinline__ F3 sample_sky(const SceneDev& sc, F3 r) {
     i00 = sky_tap_index(layer, x0, y0, W, H); i10 = sky_tap_index(layer, x0 + 1, y0, W, H);
     i01 = sky_tap_index(layer, x0, y0 + 1, W, H); i11 = sky_tap_index(layer, x0 + 1, y0 + 1, W, H);
   }
-  const uchar4 a = sc.sky[i00 == SKY_CORNER ? 0u : i00], b = sc.sky[i10 == SKY_CORNER ? 0u : i10];
-  const uchar4 c = sc.sky[i01 == SKY_CORNER ? 0u : i01], d = sc.sky[i11 == SKY_CORNER ? 0u : i11];
+  auto tap = [&](uint32_t i) -> uchar4 {
+    if (RT_NT_STREAMS & 4) { const uint32_t w = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(sc.sky) + i); uchar4 r; r.x = w & 255u; r.y = (w >> 8) & 255u; r.z = (w >> 16) & 255u; r.w = w >> 24; return r; }
+    return sc.sky[i];
+  };
+  const uchar4 a = tap(i00 == SKY_CORNER ? 0u : i00), b = tap(i10 == SKY_CORNER ? 0u : i10);
+  const uchar4 c = tap(i01 == SKY_CORNER ? 0u : i01), d = tap(i11 == SKY_CORNER ? 0u : i11);
   float c00x = (float)a.x, c00y = (float)a.y, c00z = (float)a.z, c10x = (float)b.x, c10y = (float)b.y, c10z = (float)b.z;
   float c01x = (float)c.x, c01y = (float)c.y, c01z = (float)c.z, c11x = (float)d.x, c11y = (float)d.y, c11z = (float)d.z;
   if (edge) {
@@ -747,7 +767,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
     s_col[threadIdx.y][lane] = miss_col;
     const uint64_t mm = __ballot(missed);
     if (lane == 0) s_miss[threadIdx.y] = mm;
-  } else if (missed) f.sample_color[sid] = miss_col;
+  } else if (missed) st_stream(&f.sample_color[sid], miss_col);
   // workgroups are handed to the XCDs round-robin in linear order
   const uint32_t shard = (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) & (N_SHARDS - 1);
   // ONE allocation per workgroup: the survivors of a tile's (up to four) samples form one run of the queue, so the 64-ray chunks
@@ -773,15 +793,15 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
         const float nn = (float)spp;
         const uint32_t p = ly * (uint32_t)f.width + x;     // = the sample id of sample 0
         store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
-        f.sample_color[p] = make_float4(0.f, 0.f, 0.f, PIXEL_DONE);
+        st_stream(&f.sample_color[p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
       }
-    } else if (missed) f.sample_color[sid] = miss_col;
+    } else if (missed) st_stream(&f.sample_color[sid], miss_col);
   }
   if (survive) {
     const uint32_t v = shard * f.shard_cap + slot;
     // (with entry lists the ray carries its tile instead of tmax, which is the constant 10000 of src/shader.rgen:87)
-    f.ray_o[0][v] = make_float4(u.position[0], u.position[1], u.position[2], f.entry != nullptr ? __uint_as_float(tile) : 10000.0f);
-    f.ray_d[0][v] = make_float4(d.x, d.y, d.z, __uint_as_float(sid));
+    st_stream(&f.ray_o[0][v], make_float4(u.position[0], u.position[1], u.position[2], f.entry != nullptr ? __uint_as_float(tile) : 10000.0f));
+    st_stream(&f.ray_d[0][v], make_float4(d.x, d.y, d.z, __uint_as_float(sid)));
   }
 }
 
@@ -925,7 +945,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       shard = (shard + 1u) & (N_SHARDS - 1); tried++;
     }
     if (lane < pf_count) {
-      pf_o = a.ray_o[pf_base + lane]; pf_d = a.ray_d[pf_base + lane];
+      pf_o = ld_stream(&a.ray_o[pf_base + lane]); pf_d = ld_stream(&a.ray_d[pf_base + lane]);
       if (ENTRY && MODE == MODE_SHADOW) pf_e = a.sh_e[pf_base + lane];
     }
   };
@@ -943,18 +963,18 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     if (lane < out_count) {
       const float4 r = s_out[wave][lane];
       const int2 k = s_outq[wave][lane];
-      if (MODE == MODE_CLOSEST) { a.hit_a[k.x] = r; a.hit_inst[k.x] = k.y; }
+      if (MODE == MODE_CLOSEST) { st_stream(&a.hit_a[k.x], r); st_stream(&a.hit_inst[k.x], k.y); }
       else if (MODE == MODE_SHADOW) {
         // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit.  The light term of the
         // shadow-queue entry is fetched here, once per result burst, instead of riding along in registers.
         // (the entry holds tmpColor for the lit case; the shadowed case keeps Iamb*ka — of the tagged material when a table is set)
         float cr = 0.08f, cg = 0.24f, cb = 0.08f;
         if (r.x != 0.0f || a.sc.n_materials != 0) {
-          const float4 shc = a.sh_c[(uint32_t)k.y];
+          const float4 shc = ld_stream(&a.sh_c[(uint32_t)k.y]);
           if (r.x != 0.0f) { cr = shc.x; cg = shc.y; cb = shc.z; }
           else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); cr = amb.x; cg = amb.y; cb = amb.z; }
         }
-        a.sample_color[(uint32_t)k.x] = make_float4(cr, cg, cb, 1.0f);
+        st_stream(&a.sample_color[(uint32_t)k.x], make_float4(cr, cg, cb, 1.0f));
       }
       else { HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = (int)__float_as_uint(r.w); h.inst = k.y; a.raw_out[k.x] = h; }
     }
@@ -1572,7 +1592,7 @@ __global__ __launch_bounds__(256) void k_packet(TraceArgs a) {
     }
     // ---- results: one coalesced store per lane
     if (on) {
-      if (MODE == MODE_CLOSEST) { a.hit_a[q] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim)); a.hit_inst[q] = best_inst; }
+      if (MODE == MODE_CLOSEST) { st_stream(&a.hit_a[q], make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim))); st_stream(&a.hit_inst[q], best_inst); }
       else if (MODE == MODE_SHADOW) {
         // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
         float cr = 0.08f, cg = 0.24f, cb = 0.08f;
@@ -1581,7 +1601,7 @@ __global__ __launch_bounds__(256) void k_packet(TraceArgs a) {
           if (best_inst < 0) { cr = shc.x; cg = shc.y; cb = shc.z; }
           else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); cr = amb.x; cg = amb.y; cb = amb.z; }
         }
-        a.sample_color[__float_as_uint(rd.w)] = make_float4(cr, cg, cb, 1.0f);
+        st_stream(&a.sample_color[__float_as_uint(rd.w)], make_float4(cr, cg, cb, 1.0f));
       } else { HitRec h; h.t = best_t; h.u = best_u; h.v = best_v; h.prim = best_prim; h.inst = best_inst; a.raw_out[q] = h; }
     }
   }
@@ -1711,8 +1731,8 @@ __global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
     if (lane < out_count) {
       const float4 r = s_out[wave][lane];
       const int2 k = s_outq[wave][lane];
-      if (MODE == MODE_CLOSEST) { a.hit_a[k.x] = r; a.hit_inst[k.x] = k.y; }
-      else if (MODE == MODE_SHADOW) a.sample_color[k.x] = r;
+      if (MODE == MODE_CLOSEST) { st_stream(&a.hit_a[k.x], r); st_stream(&a.hit_inst[k.x], k.y); }
+      else if (MODE == MODE_SHADOW) st_stream(&a.sample_color[k.x], r);
       else { HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = (int)__float_as_uint(r.w); h.inst = k.y; a.raw_out[k.x] = h; }
     }
     out_count = 0;
@@ -1907,17 +1927,17 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
     uint32_t sh_ent = ENTRY_FROM_ROOT;
     uint32_t sid = SID_DEAD;
     if (base + lane < n) {
-      const float4 rd = f.ray_d[cur][q];
+      const float4 rd = ld_stream(&f.ray_d[cur][q]);
       sid = __float_as_uint(rd.w);
       const F3 d = mk3(rd.x, rd.y, rd.z);
-      const int inst = f.hit_inst[q];
+      const int inst = ld_stream(&f.hit_inst[q]);
       if (inst < 0) {
         // src/shader.rmiss:11 + src/shader.rgen:90-94
         const F3 c = sample_sky(a.sc, mk3(d.x, d.y, -d.z));
-        f.sample_color[sid] = make_float4(c.x, c.y, c.z, 1.0f);
+        st_stream(&f.sample_color[sid], make_float4(c.x, c.y, c.z, 1.0f));
       } else {
         // src/shader.rchit:50-96
-        const float4 h = f.hit_a[q];
+        const float4 h = ld_stream(&f.hit_a[q]);
         const InstanceDev* I = a.sc.inst + inst;
         const uint32_t prim = __float_as_uint(h.w);
         const uint32_t* ix = a.sc.idx + I->first_index + 3u * prim;
@@ -1944,7 +1964,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
         if (type == 0u) {
           // src/shader.rgen:97-131
           if (dot3(d, N) >= 0.0f) {
-            f.sample_color[sid] = make_float4(0.08f, 0.24f, 0.08f, 1.0f);
+            st_stream(&f.sample_color[sid], make_float4(0.08f, 0.24f, 0.08f, 1.0f));
           } else {
             no = fma3(0.01f, N, P);
             const F3 toL = sub3(mk3(U.light_position[0], U.light_position[1], U.light_position[2]), P);
@@ -2005,13 +2025,13 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
           push_next = true;
         } else {
           // unknown type: the reference loop re-traces the unchanged ray until the bounce budget ends
-          const float4 ro = f.ray_o[cur][q];
+          const float4 ro = ld_stream(&f.ray_o[cur][q]);
           no = mk3(ro.x, ro.y, ro.z); nd = d; push_next = true;
         }
         if (push_next && last) {
           // loop of src/shader.rgen:84 ends: tmpColor keeps Iamb*ka
           push_next = false;
-          f.sample_color[sid] = make_float4(0.08f, 0.24f, 0.08f, 1.0f);
+          st_stream(&f.sample_color[sid], make_float4(0.08f, 0.24f, 0.08f, 1.0f));
         }
       }
     }
@@ -2019,15 +2039,15 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
     const uint32_t slot_n = wave_alloc(push_next, f.counters + cnt_tail(a.bounce + 1, (int)shard));
     if (push_next) {
       const uint32_t v = shard * f.shard_cap + slot_n;
-      f.ray_o[nxt][v] = make_float4(no.x, no.y, no.z, 10000.0f);
-      f.ray_d[nxt][v] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
+      st_stream(&f.ray_o[nxt][v], make_float4(no.x, no.y, no.z, 10000.0f));
+      st_stream(&f.ray_d[nxt][v], make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid)));
     }
     const uint32_t slot_s = wave_alloc(push_shadow, f.counters + cnt_tail(Q_SHADOW, (int)shard));
     if (push_shadow) {
       const uint32_t v = shard * f.shard_cap + slot_s;
-      f.sh_o[v] = make_float4(no.x, no.y, no.z, sh_tmax);
-      f.sh_d[v] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid));
-      f.sh_c[v] = make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w);
+      st_stream(&f.sh_o[v], make_float4(no.x, no.y, no.z, sh_tmax));
+      st_stream(&f.sh_d[v], make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid)));
+      st_stream(&f.sh_c[v], make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w));
       if (f.sh_e != nullptr) f.sh_e[v] = sh_ent;
     }
   }
@@ -2104,7 +2124,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
   if (p < npx && f.sample_color[p].w != PIXEL_DONE) {   // (PIXEL_DONE: every sample of the pixel was a miss and k_raygen stored the pixel)
     float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
     for (uint32_t i = 0; i < u.samples_per_pixel; i++) {
-      const float4 c = f.sample_color[(size_t)i * npx + p];
+      const float4 c = ld_stream(&f.sample_color[(size_t)i * npx + p]);
       r += c.x; g += c.y; b += c.z; al += c.w;
     }
     const float nn = (float)u.samples_per_pixel;

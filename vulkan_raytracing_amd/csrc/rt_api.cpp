@@ -291,14 +291,19 @@ int alloc_scene_arrays(rt_ctx* c);
 // Cache-line layout of a mesh's quantized nodes: four 32-byte nodes share a 128-byte line of the vector L1, and the step a walk takes
 // most often is parent -> child.  Nodes are laid out in TREELETS of a node and its interior children (1-3 nodes, never split across a
 // line; lines are filled greedily, treelets in depth-first order, a treelet's grandchildren are the roots of the next ones), so every
-// second step of a descent stays inside the line the previous one fetched.  Unused slots repeat node 0 (never referenced, valid for
-// walkers that scan the array).  The root stays node 0; any numbering gives the same hits.
+// second step of a descent stays inside the line the previous one fetched.  One-node treelets (a node over two leaves: half of all
+// nodes, and always a line fetch of their own) fill the slots larger treelets leave empty, so the array grows by a fraction of a
+// per cent only — the L2 of an XCD (4 MB) is the cache the deep levels live in.  A slot nothing fits repeats node 0 (never
+// referenced, valid for walkers that scan the array).  The root stays node 0; any numbering gives the same hits.
 static std::vector<BvhNodeQ> treelet_layout(const std::vector<BvhNodeQ>& in) {
   if (in.size() < 4) return in;
   std::vector<BvhNodeQ> out;
-  out.reserve(in.size() + in.size() / 2);
+  out.reserve(in.size() + 8);
   std::vector<int32_t> new_of(in.size(), -1);
-  std::vector<int32_t> todo;   // treelet roots, depth-first
+  std::vector<int32_t> todo;     // treelet roots, depth-first
+  std::vector<int32_t> singles;  // treelets of ONE node (both children are leaves: half of all nodes) waiting for a slot a larger treelet left empty
+  size_t singles_at = 0;
+  auto place = [&](int32_t old) { new_of[old] = (int32_t)out.size(); out.push_back(in[old]); };
   todo.push_back(0);
   while (!todo.empty()) {
     const int32_t r = todo.back(); todo.pop_back();
@@ -307,15 +312,21 @@ static std::vector<BvhNodeQ> treelet_layout(const std::vector<BvhNodeQ>& in) {
     if (q.child0 >= 0) kids[nk++] = q.child0;
     if (q.child1 >= 0 && q.child1 != q.child0) kids[nk++] = q.child1;
     const size_t size = 1 + (size_t)nk;
-    if ((out.size() & 3u) + size > 4u) while (out.size() & 3u) out.push_back(in[0]);
-    new_of[r] = (int32_t)out.size(); out.push_back(q);
-    for (int k = 0; k < nk; k++) { new_of[kids[k]] = (int32_t)out.size(); out.push_back(in[kids[k]]); }
+    if (size == 1 && r != 0) {
+      if (out.size() & 3u) place(r); else singles.push_back(r);   // into the open line if there is one, else wait for a gap
+      continue;
+    }
+    if ((out.size() & 3u) + size > 4u)
+      while (out.size() & 3u) { if (singles_at < singles.size()) place(singles[singles_at++]); else out.push_back(in[0]); }
+    place(r);
+    for (int k = 0; k < nk; k++) place(kids[k]);
     for (int k = nk - 1; k >= 0; k--) {   // the grandchildren start treelets of their own (first child's subtree first)
       const BvhNodeQ& c = in[kids[k]];
       if (c.child1 >= 0 && c.child1 != c.child0) todo.push_back(c.child1);
       if (c.child0 >= 0) todo.push_back(c.child0);
     }
   }
+  while (singles_at < singles.size()) place(singles[singles_at++]);
   for (BvhNodeQ& q : out) {
     if (q.child0 >= 0) q.child0 = new_of[q.child0];
     if (q.child1 >= 0) q.child1 = new_of[q.child1];
@@ -334,6 +345,7 @@ int link_blas(rt_ctx* c) {
     if (!m.built) continue;
     if (!m.gpu_built) quantize_bvh2(m.bvh, m.qnodes, m.q_lo, m.q_scale);
     laid[mi] = line_layout ? treelet_layout(m.qnodes) : m.qnodes;
+    if (getenv("RT_BUILD_TIMING")) fprintf(stderr, "[link_blas] mesh %zu: %zu nodes, %zu slots in the cache-line layout\n", mi, m.qnodes.size(), laid[mi].size());
     gap_from[mi] = nn;
     nn = (nn + 3u) & ~(size_t)3u;   // every mesh starts on a line
     m.node_base = (int32_t)nn; m.tri_base = (uint32_t)nt; m.node_base4 = (int32_t)nn4;
