@@ -1319,6 +1319,64 @@ def test_entry_points_are_result_identical(ctx):
     both(256, 256)
 
 
+def test_kept_shadow_entry_records_follow_the_light_and_the_instances(ctx):
+    """rt_set_param "shadow_entry" 2 (the default): the records of the cube around the light depend on the light, the instances and the
+    trees only, so they are KEPT while those stand still — built in the second consecutive frame with the same key, used from then on
+    (whatever the camera does), dropped the moment the light moves or rt_set_instances runs (an animated loop never builds them).
+    Every frame of a sequence that mixes all of that equals the frame rendered without records, and the shadow rays' node visits
+    tell which frames used them."""
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 0, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 320, 200
+    base_u = sp.uniforms.copy()
+    anim = host.SceneAnimation(); anim.animate(0.45)
+
+    def frame(mode):
+        ctx.set_param("shadow_entry", mode)
+        img, st = ctx.trace(W, H, counting=True)
+        return img, st.node_visits_shadow / max(1, st.rays_shadow)
+
+    try:
+        ref, v_root = frame(0)
+        ctx.set_param("shadow_entry", 2)           # (resets what is kept)
+        seq = []
+        img, v = frame(2); seq.append(v); assert np.array_equal(img, ref)      # first frame with this key: from the TLAS root
+        img, v = frame(2); seq.append(v); assert np.array_equal(img, ref)      # second: built and used
+        img, v = frame(2); seq.append(v); assert np.array_equal(img, ref)      # third: kept
+        assert seq[0] == v_root and seq[1] < 0.85 * v_root and seq[2] == seq[1], (v_root, seq)
+        # the camera moves: the records do not depend on it
+        u = base_u.copy(); u[0]["position"][:3] = np.asarray(u[0]["position"][:3]) + np.float32([0.4, 0.2, -0.3])
+        sp.set_uniforms(u)
+        ref_cam, v_cam_root = frame(0)
+        ctx.set_param("shadow_entry", 2)
+        frame(2); img, v = frame(2)
+        assert np.array_equal(img, ref_cam) and v < 0.85 * v_cam_root
+        img, v2 = frame(2)
+        assert np.array_equal(img, ref_cam) and v2 == v
+        # the light moves: dropped at once, rebuilt one frame later
+        u2 = u.copy(); u2[0]["light_position"][:3] = (1.5, 3.0, 4.0)
+        sp.set_uniforms(u2)
+        ref_l, v_l_root = frame(0)
+        ctx.set_param("shadow_entry", 2)
+        sp.set_uniforms(u); frame(2); frame(2)                                  # records for the old light exist again
+        sp.set_uniforms(u2)
+        img, va = frame(2); assert np.array_equal(img, ref_l) and va == v_l_root
+        img, vb = frame(2); assert np.array_equal(img, ref_l) and vb < 0.85 * v_l_root
+        # the instances move every frame (the reference's loop): never built, every frame exact
+        for k in range(3):
+            anim.animate(0.45 + 0.01 * (k + 1))
+            ctx.set_instances(anim.instances((0, 1)), update=True)
+            img2, vk = frame(2)
+            ctx.set_param("shadow_entry", 0)
+            img0, st0 = ctx.trace(W, H, counting=True)
+            ctx.set_param("shadow_entry", 2)
+            assert np.array_equal(img2, img0)
+            assert vk == st0.node_visits_shadow / max(1, st0.rays_shadow)
+    finally:
+        ctx.set_param("shadow_entry", 2)
+        sp.set_uniforms(base_u)
+
+
 def test_shadow_entry_points_are_result_identical(ctx):
     """Shadow rays all end (within 0.01) at the light, so k_entry also gives every tile of a cube around the light an entry list
     and k_shade tells each shadow ray its tile (rt_set_param "shadow_entry", default on; "light_tiles" per cube side).  Any-hit
@@ -1360,7 +1418,7 @@ def test_shadow_entry_points_are_result_identical(ctx):
             assert np.array_equal(o[1][0], out[1][0])
         ctx.set_param("light_tiles", 128)
     finally:
-        ctx.set_param("shadow_entry", 0); ctx.set_param("light_tiles", 128)
+        ctx.set_param("shadow_entry", 2); ctx.set_param("light_tiles", 128)
         sp.set_uniforms(base_u)
     wl = workloads.make("cfg5", RES)
     wl.apply(ctx, sky=scenes.synthetic_skybox(64))

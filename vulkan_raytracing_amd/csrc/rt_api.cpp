@@ -171,9 +171,10 @@ struct rt_ctx {
   bool tail_full_grid = false;
   int entry_max_instances = 8;   // "entry_max_instances": scenes with more instances walk from the TLAS root
   int entry_points = 1;          // 1: k_entry gives every covered tile a list of deep subtrees and its primary rays start there (result-identical)
-  int shadow_entry = 0;          // 1: ... and every tile of a cube around the light one for the shadow rays (needs entry_points).  Off by default:
-                                 // measured, it takes a third off the node visits of the shadow rays and nothing off the time of their kernel, while
-                                 // the six extra views cost every frame (and every 1/N shard of a frame) their k_cover / k_entry work
+  int shadow_entry = 2;          // ... and every tile of a cube around the light one for the shadow rays (needs entry_points): 0 off; 1 rebuilt in every frame
+                                 // (the six extra views cost every frame, and every 1/N shard of a frame, more k_cover / k_entry work than the shadow kernel
+                                 // saves); 2 (default) kept while the light and the instances stand still (LightKey below): a static scene pays for them
+                                 // once, a scene that moves every frame never
   int light_tiles = LIGHT_TILES_DEFAULT;   // tiles per side of a face of that cube
   EntryRec* d_entry = nullptr;   // one record per 8x8 tile of this slot's largest frame so far
   size_t entry_alloc_tiles = 0;
@@ -202,6 +203,14 @@ struct rt_ctx {
   // as long as inst_gen[parity] has not moved: one later rt_set_instances writes the other parity)
   struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; } last_frame{};
   uint64_t inst_gen[2] = {0, 0};  // bumped whenever the records of that parity are rewritten
+  // shadow_entry 2: the records of the cube around the light depend on the light, the instances and the trees only — like the TLAS they are
+  // kept while those stand still: built in the second consecutive frame with the same key, used from then on, dropped when the key moves
+  struct LightKey {
+    float light[3] = {0, 0, 0}; uint64_t gen = 0; int parity = -1, n_inst = 0, tiles = 0;
+    bool operator==(const LightKey& o) const { return light[0] == o.light[0] && light[1] == o.light[1] && light[2] == o.light[2] && gen == o.gen && parity == o.parity && n_inst == o.n_inst && tiles == o.tiles; }
+  };
+  LightKey light_key_seen, light_key_built;
+  bool light_built = false;
   bool tail_disabled = false;    // a k_tail barrier gave up once: this context keeps to per-bounce launches from then on
   bool frame_rerendered = false; // collect_stats rendered the pending frame again (after a k_tail fault): copies of it are stale
   uint32_t tail_faults = 0;
@@ -832,7 +841,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       if (light_tiles_total > c->light_alloc_tiles) {
         if (c->d_light_entry) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_light_entry)); c->d_light_entry = nullptr; c->light_alloc_tiles = 0; }
         HIP_TRY(c, hipMalloc((void**)&c->d_light_entry, light_tiles_total * sizeof(EntryRec)));
-        c->light_alloc_tiles = light_tiles_total;
+        c->light_alloc_tiles = light_tiles_total; c->light_built = false;
       }
       f.light_entry = c->d_light_entry; f.light_tiles = LT;   // (f.sh_e: allocated with the ray queues)
       // a shadow ray starts 0.01 N off the shaded point and runs parallel to the line from that point to the light
@@ -855,7 +864,20 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         le.records = c->d_light_entry + (size_t)face * LT * LT;
         le.cover = f.cover + lc.mask_offset; le.cover_tiles_x = LT;
       }
-      cv.n = ENTRY_VIEWS; ev.n = ENTRY_VIEWS;
+      bool build = true;
+      if (c->shadow_entry == 2) {
+        rt_ctx::LightKey key;
+        for (int k = 0; k < 3; k++) key.light[k] = u.light_position[k];
+        key.gen = c->inst_gen[frame_parity]; key.parity = frame_parity; key.n_inst = sc.n_inst; key.tiles = LT;
+        const bool have = c->light_built && key == c->light_key_built;
+        const bool stable = key == c->light_key_seen;
+        if (!again) c->light_key_seen = key;
+        if (again != nullptr) { build = false; if (!have) { f.light_entry = nullptr; f.light_tiles = 0; } }   // a re-render uses what exists, builds nothing
+        else if (have) build = false;
+        else if (stable) { c->light_key_built = key; c->light_built = true; }
+        else { build = false; c->light_built = false; f.light_entry = nullptr; f.light_tiles = 0; }   // the scene moves: this frame's shadow rays walk from the TLAS root
+      }
+      if (build) { cv.n = ENTRY_VIEWS; ev.n = ENTRY_VIEWS; }
     }
   }
   // far-ray logic in this frame's kernels only if some ray can be far (a re-render decides again from the same inputs)
@@ -1403,12 +1425,12 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
   if (k == "packet_trace") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2"); c->cfg.packet = value; return RT_OK; }
   if (k == "packet_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_blocks_per_cu must be 1..16"); c->cfg.packet_blocks = c->n_cu * value; return RT_OK; }
-  if (k == "shadow_entry") { c->shadow_entry = value != 0; return RT_OK; }
+  if (k == "shadow_entry") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "shadow_entry must be 0, 1 or 2"); c->shadow_entry = value; c->light_built = false; return RT_OK; }
   if (k == "entry_max_instances") { if (value < 1 || value >= (int)ENTRY_NO_INST) return fail(c, RT_ERR_INVALID_ARGUMENT, "entry_max_instances out of range"); c->entry_max_instances = value; return RT_OK; }
   if (k == "light_tiles") {
     if (value < 8 || value > 512) return fail(c, RT_ERR_INVALID_ARGUMENT, "light_tiles must be 8..512");
     { int q = quiesce(c); if (q) return q; }
-    c->light_tiles = value; return RT_OK;
+    c->light_tiles = value; c->light_built = false; return RT_OK;
   }
   if (k == "tail_kernel") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "tail_kernel must be 0 (off), 1 (auto) or 2 (always)"); c->tail_mode = value; return RT_OK; }
   if (k == "debug_force_tail_fault") { c->debug_force_tail_fault = value != 0; if (value == 2) c->tail_disabled = false; return RT_OK; }
