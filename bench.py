@@ -485,7 +485,11 @@ def main(args):
                              "ray_classes": "value counts every traceRayEXT-equivalent: primary + secondary (bounce) + shadow rays; 'secondary' in the metric string means both",
                              "parallelism": "interleaved %d-row bands over %d GPU(s), one scene per GPU, one RCCL gather per frame, %d frame slots in flight per GPU" % (rig.band, n, P),
                              "frames_in_flight": P, "device": ctx.device_info,
-                             "animated_loop": "per step: animate (fixed dt 1/60 s) -> rt_set_instances(update=1) = TLAS refit -> rt_set_uniforms -> frame; src/main.cpp:2836-2861, 2901-2903"}}
+                             "animated_loop": "per step: animate (fixed dt 1/60 s) -> rt_set_instances(update=1) = TLAS refit -> rt_set_uniforms -> frame; src/main.cpp:2836-2861, 2901-2903",
+                             "kept_between_frames": "what depends on the light, the instances and the trees only, as in the reference: BLAS, TLAS, and (rt_set_param shadow_entry 2, "
+                                                    "the default) the shadow rays' entry records around the light, rebuilt when the light or an instance moves — the timed "
+                                                    "frames are static, so `value` has them; the animated loop moves the instances every step and never builds them "
+                                                    "(animated_value); nothing that depends on the camera or on pixels is kept"}}
     # ---- roofline of the dominant kernel (closest-hit traversal), rank 0's shard -----------------
     if rank == 0:
         # (1) isolated frames: the same shard, one frame at a time on slot 0, HIP events around every kernel

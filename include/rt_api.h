@@ -228,7 +228,7 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
  * "entry_points" 1 (default; needs primary_cover) = every marked tile gets an entry record — the handful of deep subtrees of the
  * TLAS / the nearest instance's BLAS that the tile's beam of primary rays can touch — and its primary rays start their walk there
  * instead of at the TLAS root; "shadow_entry" = the same for the shadow rays, from the tiles of a cube of "light_tiles" (8..512,
- * default 128) tiles per side around the light: 0 = off, 1 = rebuilt in every frame (measured: costs more than it saves), 2 (default) =
+ * default 256) tiles per side around the light: 0 = off, 1 = rebuilt in every frame (measured: costs more than it saves), 2 (default) =
  * built once the light and the instances have stood still for two frames and kept until either moves (they do not depend on the camera); "packet_trace" 1 = primary and shadow rays are
  * walked by the packet kernel (one wavefront per 64-ray chunk; default 0: measured slower), 2 = rt_intersect's rays too;
  * "output_bgra8" 1 = like "output_rgba8" in the byte order of a B8G8R8A8 surface (surfaceFormatList[0] is normally that,

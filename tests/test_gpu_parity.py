@@ -1416,9 +1416,9 @@ def test_shadow_entry_points_are_result_identical(ctx):
             ctx.set_param("light_tiles", lt)
             o = both()
             assert np.array_equal(o[1][0], out[1][0])
-        ctx.set_param("light_tiles", 128)
+        ctx.set_param("light_tiles", 256)
     finally:
-        ctx.set_param("shadow_entry", 2); ctx.set_param("light_tiles", 128)
+        ctx.set_param("shadow_entry", 2); ctx.set_param("light_tiles", 256)
         sp.set_uniforms(base_u)
     wl = workloads.make("cfg5", RES)
     wl.apply(ctx, sky=scenes.synthetic_skybox(64))

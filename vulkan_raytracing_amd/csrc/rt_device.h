@@ -143,7 +143,7 @@ constexpr uint32_t ENTRY_REVERSE = 0x80000000u;      // per-ray flag: take the i
 struct alignas(16) EntryRec { int32_t w[2 + ENTRY_WORDS]; };
 static_assert(sizeof(EntryRec) == 32, "EntryRec must be 32 bytes");
 constexpr int ENTRY_VIEWS = 7;                       // camera + 6 light faces
-constexpr int LIGHT_TILES_DEFAULT = 128;             // tiles per side of a light face (rt_set_param "light_tiles")
+constexpr int LIGHT_TILES_DEFAULT = 256;             // tiles per side of a light face (rt_set_param "light_tiles")
 constexpr int N_SHARDS = 8;
 constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: one 128-byte line each
 constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounceCount <= 69)
