@@ -946,7 +946,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     }
     if (lane < pf_count) {
       pf_o = ld_stream(&a.ray_o[pf_base + lane]); pf_d = ld_stream(&a.ray_d[pf_base + lane]);
-      if (ENTRY && MODE == MODE_SHADOW) pf_e = a.sh_e[pf_base + lane];
+      if (ENTRY && MODE == MODE_SHADOW) pf_e = (uint32_t)ld_stream(reinterpret_cast<const int*>(a.sh_e) + pf_base + lane);
     }
   };
   auto promote = [&]() {
