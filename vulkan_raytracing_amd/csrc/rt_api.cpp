@@ -798,7 +798,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // more than the records save: measured 1.86 vs 1.80 ms per frame, profiles/r03_experiments.txt — so records are for scenes of few instances)
   const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && sc.n_inst <= c->entry_max_instances;
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
-  const bool light_on = entry_on && c->shadow_entry && std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2]);
+  // (kept records are paid once, so they also serve scenes of more instances than the per-frame camera records are worth building for)
+  const bool light_on = cover_on && c->entry_points && c->cfg.variant == 0 && (entry_on || c->shadow_entry == 2) && c->shadow_entry &&
+                        std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2]);
   const int LT = c->light_tiles;
   const uint32_t cam_words = 1u + (uint32_t)((((size_t)((W + 7) / 8) * (size_t)((H + 7) / 8)) + 31) / 32);
   const uint32_t face_words = 1u + (uint32_t)(((size_t)LT * LT + 31) / 32);
@@ -819,15 +821,16 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     f.cover_words = c->cover_alloc_words; f.cover_tiles_x = (W + 7) / 8;
   }
   EntryViews ev{};
-  if (entry_on && f.cover != nullptr) {
-    const size_t tiles_local = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
+  if ((entry_on || light_on) && f.cover != nullptr) {
+    const size_t tiles_local = entry_on ? (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8) : 0;
     if (tiles_local > c->entry_alloc_tiles) {
       if (c->d_entry) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_entry)); c->d_entry = nullptr; c->entry_alloc_tiles = 0; }
       HIP_TRY(c, hipMalloc((void**)&c->d_entry, tiles_local * sizeof(EntryRec)));
       c->entry_alloc_tiles = tiles_local;
     }
-    f.entry = c->d_entry;
-    EntryArgs& ea = ev.v[0];
+    f.entry = entry_on ? c->d_entry : nullptr;
+    EntryArgs& ea = ev.v[0];   // (without camera records view 0 stays empty: no tiles, no blocks with work)
+    if (entry_on) {
     for (int k = 0; k < 3; k++) ea.cam[k] = ca.cam[k];
     for (int k = 0; k < 9; k++) ea.inv[k] = ca.inv[k];
     for (int k = 0; k < 3; k++) { ea.basis[k] = u.right[k]; ea.basis[3 + k] = u.up[k]; ea.basis[6 + k] = u.forward[k]; }
@@ -835,6 +838,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     ea.width = W; ea.height = H; ea.tiles_x = (W + 7) / 8; ea.tile_rows = (rows + 7) / 8;
     ea.band_rows = band_rows; ea.shard = shard; ea.n_shards = n_shards;
     ea.records = c->d_entry; ea.cover = f.cover; ea.cover_tiles_x = f.cover_tiles_x;
+    }
     ev.n = 1;
     if (light_on) {
       const size_t light_tiles_total = (size_t)6 * LT * LT;
@@ -903,7 +907,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     {
       Span sp(c, CAT_RAYGEN, s);
       if (f.cover) launch_cover(sc, cv, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
-      if (f.entry) launch_entry(sc, ev, s);
+      if (f.entry || ev.n > 1) launch_entry(sc, ev, s);
       launch_raygen(sc, f, u, s);
     }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
