@@ -169,7 +169,7 @@ struct rt_ctx {
   int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
   int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
   bool tail_full_grid = false;
-  int entry_max_instances = 8;   // "entry_max_instances": scenes with more instances walk from the TLAS root
+  int entry_max_instances = 32;  // "entry_max_instances": scenes with more instances walk from the TLAS root (32 = what the kernels stage in LDS; cfg5's 17 instances: -1.3 %)
   int entry_points = 1;          // 1: k_entry gives every covered tile a list of deep subtrees and its primary rays start there (result-identical)
   int shadow_entry = 2;          // ... and every tile of a cube around the light one for the shadow rays (needs entry_points): 0 off; 1 rebuilt in every frame
                                  // (the six extra views cost every frame, and every 1/N shard of a frame, more k_cover / k_entry work than the shadow kernel
