@@ -16,12 +16,28 @@
 // 3: MODE 1 plus `valu` dependent fmas per step (the box tests); 4: two requests per step like MODE 1, but issued by lane PAIRS: in the
 // first instruction both lanes of a pair fetch the two halves of the even lane's node, in the second those of the odd lane's node
 // (adjacent 16-byte pieces from adjacent lanes: one 32-byte access per pair if the address unit merges them), halves exchanged by DPP (quad_perm 1,0,3,2)
+// MODE 5: the same chain with the nodes in LDS (the first 512 nodes, 16 KB, copied by the workgroup): two ds_read_b128 per step — what a
+// walk over LDS-staged subtrees would pay per visit instead
 template <int MODE>
 __global__ __launch_bounds__(256) void k_chase(const uint4* __restrict__ nodes, uint32_t mask, uint32_t share_shift, int steps, int valu, uint32_t* out) {
   const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
   // lanes that share a node start from the same index and follow the same chain
   uint32_t cur = ((tid >> share_shift) * 2654435761u) & mask;
   uint32_t acc = 0; float f = 1.0f;
+  __shared__ uint4 s_nodes[MODE == 5 ? 1024 : 1];
+  if (MODE == 5) {
+    for (uint32_t i = threadIdx.x; i < 1024u; i += 256u) s_nodes[i] = nodes[i];
+    __syncthreads();
+    cur &= 511u;
+    for (int s = 0; s < steps; s++) {
+      const uint4 a = s_nodes[2u * cur], b = s_nodes[2u * cur + 1u];
+      acc += a.y ^ b.z ^ a.z ^ a.w ^ b.x ^ b.y;
+      cur = (a.x + b.w) & 511u;
+    }
+    if (acc == 0x12345678u) out[0] = acc;
+    if (tid == 0) out[1] = cur;
+    return;
+  }
   for (int s = 0; s < steps; s++) {
     const uint4 a = nodes[2u * cur];
     uint4 b = make_uint4(0, 0, 0, 0);
@@ -73,6 +89,7 @@ int main() {
         case 1: k_chase<1><<<grid, 256>>>(d, mask, share_shift, steps, valu, d_out); break;
         case 2: k_chase<2><<<grid, 256>>>(d, mask, share_shift, steps, valu, d_out); break;
         case 4: k_chase<4><<<grid, 256>>>(d, mask, share_shift, steps, valu, d_out); break;
+        case 5: k_chase<5><<<grid, 256>>>(d, mask, share_shift, steps, valu, d_out); break;
         default: k_chase<3><<<grid, 256>>>(d, mask, share_shift, steps, valu, d_out); break;
       }
       CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
@@ -80,7 +97,7 @@ int main() {
     }
     const double ns_step = best * 1e6 / steps;                      // every wave does `steps` steps, all waves concurrently
     const double cyc = ns_step * ghz;
-    const int req = mode == 0 ? 1 : 2;
+    const int req = mode == 0 ? 1 : 2;   // (mode 5: two LDS reads)
     const double lane_req_per_cu_cycle = (double)wg_per_cu * 4 * 64 * req / cyc;
     printf("mode %d  set %8.2f MB  lanes/node %2u  wg/CU %d  valu %3d : %8.1f ns = %7.0f cycles per wave-step, %.3f lane requests per CU cycle\n",
            mode, (double)(1u << log2_nodes) * 32 / 1048576.0, 1u << share_shift, wg_per_cu, valu, ns_step, cyc, lane_req_per_cu_cycle);
@@ -91,5 +108,6 @@ int main() {
   for (int wg : {1, 2, 3, 4, 5, 6, 8}) run(1, 18, 0, wg, 0);                          // occupancy
   for (int valu : {0, 32, 64, 96, 128}) run(3, 18, 0, 5, valu);                       // + dependent VALU per step
   for (int valu : {0, 64}) run(3, 9, 0, 5, valu);
+  for (int wg : {1, 3, 5}) run(5, 9, 0, wg, 0);                                        // nodes in LDS
   return 0;
 }
