@@ -1321,57 +1321,65 @@ def test_entry_points_are_result_identical(ctx):
 
 def test_kept_shadow_entry_records_follow_the_light_and_the_instances(ctx):
     """rt_set_param "shadow_entry" 2 (the default): the records of the cube around the light depend on the light, the instances and the
-    trees only, so they are KEPT while those stand still — built in the second consecutive frame with the same key, used from then on
-    (whatever the camera does), dropped the moment the light moves or rt_set_instances runs (an animated loop never builds them).
-    Every frame of a sequence that mixes all of that equals the frame rendered without records, and the shadow rays' node visits
-    tell which frames used them."""
+    trees only, so they are KEPT while those stand still — built in a context's first frame and in the second consecutive frame with a new
+    key, used from then on (whatever the camera does), dropped the moment the light moves or rt_set_instances runs (an animated loop builds
+    them once, at its first frame, and never again).  Every frame of a sequence that mixes all of that equals the frame rendered without
+    records, and the shadow rays' node visits tell which frames used them."""
     arm, _ = host.armadillo_path(RES)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 0, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
     W, H = 320, 200
     base_u = sp.uniforms.copy()
     anim = host.SceneAnimation(); anim.animate(0.45)
 
-    def frame(mode):
-        ctx.set_param("shadow_entry", mode)
+    def frame():
         img, st = ctx.trace(W, H, counting=True)
         return img, st.node_visits_shadow / max(1, st.rays_shadow)
 
+    def reference():   # the same frame without records (changing the parameter drops what is kept)
+        ctx.set_param("shadow_entry", 0)
+        out = frame()
+        ctx.set_param("shadow_entry", 2)
+        return out
+
     try:
-        ref, v_root = frame(0)
-        ctx.set_param("shadow_entry", 2)           # (resets what is kept)
+        ref, v_root = reference()
         seq = []
-        img, v = frame(2); seq.append(v); assert np.array_equal(img, ref)      # first frame with this key: from the TLAS root
-        img, v = frame(2); seq.append(v); assert np.array_equal(img, ref)      # second: built and used
-        img, v = frame(2); seq.append(v); assert np.array_equal(img, ref)      # third: kept
-        assert seq[0] == v_root and seq[1] < 0.85 * v_root and seq[2] == seq[1], (v_root, seq)
-        # the camera moves: the records do not depend on it
+        for _ in range(3):      # first frame after the reset: built at once (optimistic start); then kept
+            img, v = frame(); seq.append(v); assert np.array_equal(img, ref)
+        assert seq[0] < 0.85 * v_root and seq[1] == seq[0] and seq[2] == seq[0], (v_root, seq)
+        # the camera moves: the records do not depend on it — no rebuild, still used
         u = base_u.copy(); u[0]["position"][:3] = np.asarray(u[0]["position"][:3]) + np.float32([0.4, 0.2, -0.3])
         sp.set_uniforms(u)
-        ref_cam, v_cam_root = frame(0)
-        ctx.set_param("shadow_entry", 2)
-        frame(2); img, v = frame(2)
+        img, v = frame()
+        ref_cam, v_cam_root = reference()
         assert np.array_equal(img, ref_cam) and v < 0.85 * v_cam_root
-        img, v2 = frame(2)
-        assert np.array_equal(img, ref_cam) and v2 == v
-        # the light moves: dropped at once, rebuilt one frame later
+        frame()                                                                 # (records exist again after the reference's reset)
+        # the light moves: dropped at once (this frame walks from the TLAS root), rebuilt one frame later, kept after that
         u2 = u.copy(); u2[0]["light_position"][:3] = (1.5, 3.0, 4.0)
         sp.set_uniforms(u2)
-        ref_l, v_l_root = frame(0)
-        ctx.set_param("shadow_entry", 2)
-        sp.set_uniforms(u); frame(2); frame(2)                                  # records for the old light exist again
-        sp.set_uniforms(u2)
-        img, va = frame(2); assert np.array_equal(img, ref_l) and va == v_l_root
-        img, vb = frame(2); assert np.array_equal(img, ref_l) and vb < 0.85 * v_l_root
-        # the instances move every frame (the reference's loop): never built, every frame exact
+        img_a, va = frame()
+        img_b, vb = frame()
+        img_c, vc = frame()
+        ref_l, v_l_root = reference()
+        assert np.array_equal(img_a, ref_l) and np.array_equal(img_b, ref_l) and np.array_equal(img_c, ref_l)
+        assert va == v_l_root and vb < 0.85 * v_l_root and vc == vb, (v_l_root, va, vb, vc)
+        frame()
+        # the instances move every frame (the reference's loop): dropped, never rebuilt, every frame exact
         for k in range(3):
             anim.animate(0.45 + 0.01 * (k + 1))
             ctx.set_instances(anim.instances((0, 1)), update=True)
-            img2, vk = frame(2)
-            ctx.set_param("shadow_entry", 0)
-            img0, st0 = ctx.trace(W, H, counting=True)
-            ctx.set_param("shadow_entry", 2)
+            img2, vk = frame()
+            anim_ref = RtContext(0)
+            try:
+                sp2 = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 0, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=anim_ref, time_param=0.45)
+                anim_ref.set_param("shadow_entry", 0)
+                anim_ref.set_instances(anim.instances((0, 1)))
+                anim_ref.set_uniforms(u2)
+                img0, st0 = anim_ref.trace(W, H, counting=True)
+            finally:
+                anim_ref.close()
             assert np.array_equal(img2, img0)
-            assert vk == st0.node_visits_shadow / max(1, st0.rays_shadow)
+            assert vk == st0.node_visits_shadow / max(1, st0.rays_shadow), (k, vk)
     finally:
         ctx.set_param("shadow_entry", 2)
         sp.set_uniforms(base_u)

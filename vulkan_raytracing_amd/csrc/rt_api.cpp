@@ -204,13 +204,13 @@ struct rt_ctx {
   struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; } last_frame{};
   uint64_t inst_gen[2] = {0, 0};  // bumped whenever the records of that parity are rewritten
   // shadow_entry 2: the records of the cube around the light depend on the light, the instances and the trees only — like the TLAS they are
-  // kept while those stand still: built in the second consecutive frame with the same key, used from then on, dropped when the key moves
+  // kept while those stand still: built in a context's first frame and in the second consecutive frame with a new key, used from then on, dropped when the key moves
   struct LightKey {
     float light[3] = {0, 0, 0}; uint64_t gen = 0; int parity = -1, n_inst = 0, tiles = 0;
     bool operator==(const LightKey& o) const { return light[0] == o.light[0] && light[1] == o.light[1] && light[2] == o.light[2] && gen == o.gen && parity == o.parity && n_inst == o.n_inst && tiles == o.tiles; }
   };
   LightKey light_key_seen, light_key_built;
-  bool light_built = false;
+  bool light_built = false, light_seen_valid = false;
   bool tail_disabled = false;    // a k_tail barrier gave up once: this context keeps to per-bounce launches from then on
   bool frame_rerendered = false; // collect_stats rendered the pending frame again (after a k_tail fault): copies of it are stale
   uint32_t tail_faults = 0;
@@ -874,8 +874,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         for (int k = 0; k < 3; k++) key.light[k] = u.light_position[k];
         key.gen = c->inst_gen[frame_parity]; key.parity = frame_parity; key.n_inst = sc.n_inst; key.tiles = LT;
         const bool have = c->light_built && key == c->light_key_built;
-        const bool stable = key == c->light_key_seen;
-        if (!again) c->light_key_seen = key;
+        // (the first frame of a context builds at once — an optimistic start: a scene that turns out to move drops the records at its second frame)
+        const bool stable = !c->light_seen_valid || key == c->light_key_seen;
+        if (!again) { c->light_key_seen = key; c->light_seen_valid = true; }
         if (again != nullptr) { build = false; if (!have) { f.light_entry = nullptr; f.light_tiles = 0; } }   // a re-render uses what exists, builds nothing
         else if (have) build = false;
         else if (stable) { c->light_key_built = key; c->light_built = true; }
@@ -1429,7 +1430,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
   if (k == "packet_trace") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2"); c->cfg.packet = value; return RT_OK; }
   if (k == "packet_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_blocks_per_cu must be 1..16"); c->cfg.packet_blocks = c->n_cu * value; return RT_OK; }
-  if (k == "shadow_entry") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "shadow_entry must be 0, 1 or 2"); c->shadow_entry = value; c->light_built = false; return RT_OK; }
+  if (k == "shadow_entry") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "shadow_entry must be 0, 1 or 2"); if (value != c->shadow_entry) { c->light_built = false; c->light_seen_valid = false; } c->shadow_entry = value; return RT_OK; }
   if (k == "entry_max_instances") { if (value < 1 || value >= (int)ENTRY_NO_INST) return fail(c, RT_ERR_INVALID_ARGUMENT, "entry_max_instances out of range"); c->entry_max_instances = value; return RT_OK; }
   if (k == "light_tiles") {
     if (value < 8 || value > 512) return fail(c, RT_ERR_INVALID_ARGUMENT, "light_tiles must be 8..512");
