@@ -222,7 +222,8 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
  * "trace_blocks_per_cu" 1..8; "shade_blocks_per_cu" 1..16; "blas_builder" 1 = device builder (default:
  * rt_build_blas builds on the GPU, as the reference's DEVICE build type does, src/main.cpp:345-357 — a binned-SAH tree made level by
  * level; the environment variable RT_GPU_BVH_ALGO = 1 / 2 selects the LBVH / PLOC builders instead), 0 = host binned-SAH (threaded);
- * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids; "primary_cover" 1 (default) = before ray generation the
+ * "trace_rays_per_lane", "trace_min_blocks" size the persistent grids; "closest_blocks_per_cu" / "shadow_blocks_per_cu" cap one launch's share of
+ * it (-1 = automatic, the default: 2 per CU for launches of at most 2.5 M rays when three or more frame slots share the GPU, 0 = no cap, 1..8); "primary_cover" 1 (default) = before ray generation the
  * frontier boxes of every instance's BLAS are projected onto 8x8-pixel screen tiles and the samples of tiles no mesh can
  * project onto are shaded as misses without any box test, 0 = every primary ray is tested against the TLAS;
  * "entry_points" 1 (default; needs primary_cover) = every marked tile gets an entry record — the handful of deep subtrees of the

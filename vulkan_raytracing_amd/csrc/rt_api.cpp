@@ -163,6 +163,11 @@ struct rt_ctx {
   int32_t* d_ovf = nullptr;
   LaunchCfg cfg{};
   bool grid_user_set = false;      // "trace_blocks_per_cu" was set explicitly: keep it
+  // Per-launch caps of the persistent traversal grid (workgroups per CU).  -1 = automatic: with three or more frame slots on the GPU a launch
+  // of at most GRID_SMALL_RAYS rays (the slot's previous frame tells) takes 2 per CU instead of 3 — closest hit always, shadow only when its
+  // rays start from the kept records (a third fewer visits); measured on cfg3 (both meshes) -2.7 % / -1.6 %, cfg4's 6 M-ray launches and the
+  // animated loop's shadow rays from the TLAS root want the 3 (profiles/r03_experiments.txt).  0 = no cap, 1..8 = that many.
+  int closest_blocks_per_cu = -1, shadow_blocks_per_cu = -1;
   int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped so that the tails of every live slot on the device are always co-resident
   int tail_resident_per_cu = 0;
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
@@ -903,6 +908,14 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (rows == 0) return RT_OK;   // nothing is launched: both counter blocks stay zero
   c->cnt_parity ^= 1;
   if (f.cover_next) c->cover_parity ^= 1;   // (f.cover / f.cover_next were taken above)
+  int cap_closest = c->closest_blocks_per_cu, cap_shadow = c->shadow_blocks_per_cu;
+  {
+    constexpr unsigned long long GRID_SMALL_RAYS = 2500000ull;
+    const bool crowded = c->scene->members.size() >= 3 && !c->grid_user_set && !c->last_empty;
+    const unsigned long long prev_q0 = ((volatile unsigned long long*)c->h_stats)[STAT_QUEUE0], prev_sh = ((volatile unsigned long long*)c->h_stats)[STAT_SHADOW];
+    if (cap_closest < 0) cap_closest = (crowded && prev_q0 > 0 && prev_q0 <= GRID_SMALL_RAYS) ? 2 : 0;
+    if (cap_shadow < 0) cap_shadow = (crowded && f.light_entry != nullptr && prev_sh > 0 && prev_sh <= GRID_SMALL_RAYS) ? 2 : 0;
+  }
   {
     Span frame_span(c, CAT_FRAME, s);
     {
@@ -940,7 +953,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, cfg, tb, s);
         break;
       }
-      { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cfg, s); }
+      { LaunchCfg cc = cfg; if (b == 0 && cap_closest > 0) cc.trace_blocks = std::min(cfg.trace_blocks, c->n_cu * cap_closest);
+        Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cc, s); }
       { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
@@ -952,7 +966,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         if (live == 0) break;
       }
     }
-    { Span sp(c, CAT_SHADOW, s); launch_trace_shadow(sc, f, c->counting, cfg, s); }
+    { LaunchCfg cs = cfg; if (cap_shadow > 0) cs.trace_blocks = std::min(cfg.trace_blocks, c->n_cu * cap_shadow);
+      Span sp(c, CAT_SHADOW, s); launch_trace_shadow(sc, f, c->counting, cs, s); }
     { Span sp(c, CAT_RESOLVE, s); launch_resolve(f, u, s); }
   }
   HIP_TRY(c, hipGetLastError());
@@ -1410,6 +1425,10 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
       }
     }
     return RT_OK;
+  }
+  if (k == "closest_blocks_per_cu" || k == "shadow_blocks_per_cu") {
+    if (value < -1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, k + " must be -1 (automatic), 0 (the persistent grid) or 1..8");
+    (k[0] == 'c' ? c->closest_blocks_per_cu : c->shadow_blocks_per_cu) = value; return RT_OK;
   }
   if (k == "trace_blocks_per_cu") {
     if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_blocks_per_cu must be 1..8");
