@@ -1,9 +1,8 @@
 #!/bin/bash
-# frames in flight x hardware queues on the headline workload: tools/p_sweep.sh <tag> [bench args]
-TAG=$1; shift
-OUT=gpurun_out/psweep_$TAG; mkdir -p $OUT
-for Q in 4 8; do for P in 2 3 4 6 8; do
-  GPU_MAX_HW_QUEUES=$Q timeout -k 10 200 python3 bench.py --no-cpu-baseline --no-extras --frames-in-flight $P --steps 48 --warmup 8 "$@" > $OUT/q${Q}_p$P.json 2> $OUT/q${Q}_p$P.err
-  python3 -c "
-import json; d=json.load(open('$OUT/q${Q}_p$P.json')); print('queues $Q slots $P: ms/step %.4f  %.0f Mrays/s' % (d['ms_per_step'], d['value']))"
-done; done
+# frame slots in flight on one GPU (HIP's default 4 hardware queues, then 8 queues)
+run() { python3 bench.py --frames-in-flight $1 --steps 60 --warmup 10 --no-cpu-baseline --no-extras 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('queues ${GPU_MAX_HW_QUEUES:-default} slots $1: ms/step %.4f' % d['ms_per_step'])"; }
+unset GPU_MAX_HW_QUEUES
+for p in 3 4 5 6 8; do run $p; done
+export GPU_MAX_HW_QUEUES=8
+for p in 3 4 5 6 8; do run $p; done
