@@ -11,18 +11,40 @@ HIPFLAGS := -O3 -std=c++17 --offload-arch=$(ARCH) -ffp-contract=off -fno-slp-vec
 
 all: $(PKG)/librt_mi355x.so oracle
 
-$(PKG)/librt_mi355x.so: $(CSRC)/kernels.hip $(CSRC)/bvh_gpu.hip $(CSRC)/bvh_gpu.h $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/bvh_build.h include/rt_api.h
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/kernels.hip $(CSRC)/bvh_gpu.hip $(CSRC)/rt_api.cpp $(CSRC)/bvh_build.cpp
+# one object per source, so that a change to one file recompiles that file only (kernels.hip alone is ~25 s)
+OBJDIR   := build/obj
+DEVHDRS  := $(CSRC)/rt_device.h $(CSRC)/rt_kernels.h $(CSRC)/bvh_build.h $(CSRC)/bvh_gpu.h include/rt_api.h
+$(OBJDIR)/%.o: $(CSRC)/%.hip $(DEVHDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(OBJDIR)/%.o: $(CSRC)/%.cpp $(DEVHDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
+$(OBJDIR)/kernels.o: $(CSRC)/kernels_tile.inc
+PRODUCT_OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/rt_api.o $(OBJDIR)/bvh_build.o
+$(PKG)/librt_mi355x.so: $(PRODUCT_OBJS)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(PRODUCT_OBJS)
+
+# the traversal alternatives that measured slower (k_packet, the quad/BVH4 kernel, 4-ary records: csrc/kernels_alt.inc) are NOT in the
+# product library; `make alt` builds librt_mi355x_alt.so with them for the identity tests (RtContext(variant="alt") / RT_LIB_VARIANT=alt)
+$(OBJDIR)/kernels_alt.o: $(CSRC)/kernels.hip $(CSRC)/kernels_alt.inc $(CSRC)/kernels_tile.inc $(DEVHDRS)
+	@mkdir -p $(OBJDIR)
+	$(HIPCC) $(HIPFLAGS) -DRT_ALT_KERNELS -c -o $@ $(CSRC)/kernels.hip
+$(PKG)/librt_mi355x_alt.so: $(OBJDIR)/kernels_alt.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/rt_api.o $(OBJDIR)/bvh_build.o
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $^
+alt: $(PKG)/librt_mi355x_alt.so
+all: alt
 
 oracle:
 	$(MAKE) -C oracle all
 
+# registers, scratch, LDS and occupancy of every kernel of the product TU (tests/test_host.py holds the shipped traversal kernels to their budget)
 resource-usage:
 	$(HIPCC) $(HIPFLAGS) -c -Rpass-analysis=kernel-resource-usage -o /dev/null $(CSRC)/kernels.hip
 
 clean:
-	rm -f $(PKG)/*.so; $(MAKE) -C oracle clean
-.PHONY: all oracle clean resource-usage
+	rm -f $(PKG)/*.so; rm -rf $(OBJDIR); $(MAKE) -C oracle clean
+.PHONY: all oracle clean resource-usage alt
 
 # host-side library (OBJ/MTL ingest, camera, animation, stand-in mesh, JPEG decode) — g++ only
 HOSTSRC := $(CSRC)/host_shim.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp $(wildcard host/jpeg_decode.cpp)

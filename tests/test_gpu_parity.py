@@ -27,6 +27,15 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(scope="module")
+def ctx_alt():
+    """A context of librt_mi355x_alt.so: the product sources compiled with -DRT_ALT_KERNELS, i.e. WITH the traversal kernels that
+    measured slower and are not shipped (k_packet, the quad/BVH4 kernel, 4-ary records).  Loaded next to the product library."""
+    c = RtContext(0, variant="alt")
+    yield c
+    c.close()
+
+
 def image_report(gpu, ref):
     diff = np.abs(gpu - ref).max(axis=2)
     return {"max": float(diff.max()), "frac_within_tol": float((diff <= TOL).mean()), "frac_bit_exact": float((diff == 0).mean())}
@@ -303,8 +312,18 @@ def test_frames_in_flight_async_entry_points(ctx):
             c.close()
 
 
-def test_trace_variants_are_result_identical(ctx):
-    """BVH2/one-lane-per-ray, BVH4/four-lanes-per-ray and 4-ary-record/one-lane kernels: identical hit records and images."""
+def test_trace_variants_are_result_identical(ctx, ctx_alt):
+    """BVH2/one-lane-per-ray, BVH4/four-lanes-per-ray and 4-ary-record/one-lane kernels: identical hit records and images.  The
+    alternatives live in librt_mi355x_alt.so only; the product library refuses them, and its frames equal the alt build's."""
+    with pytest.raises(RtError):
+        ctx.set_param("trace_variant", 2)
+    with pytest.raises(RtError):
+        ctx.set_param("packet_trace", 1)
+    arm, _ = host.armadillo_path(RES)
+    scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 1, 4, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.6)
+    product_img, product_st = ctx.trace(256, 144)
+    product_rays = (product_st.rays_primary, product_st.rays_secondary, product_st.rays_shadow)
+    ctx = ctx_alt
     arm, _ = host.armadillo_path(RES)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 1, 4, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.6)
     rays = scenes.random_rays(40000, seed=33, target_radius=6.0)
@@ -319,6 +338,7 @@ def test_trace_variants_are_result_identical(ctx):
             out[v] = (g, ga["inst"] >= 0, img, (st.rays_primary, st.rays_secondary, st.rays_shadow))
     finally:
         ctx.set_param("trace_variant", 0)
+    assert np.array_equal(out[0][2], product_img) and out[0][3] == product_rays
     for v in (1, 2):
         assert np.array_equal(out[0][0], out[v][0])
         assert np.array_equal(out[0][1], out[v][1])
@@ -420,7 +440,7 @@ def test_device_built_blas_gives_identical_results(ctx, algo, monkeypatch):
     monkeypatch.setenv("RT_GPU_BVH_ALGO", algo)
     arm, _ = host.armadillo_path(RES)
     rays = scenes.random_rays(30000, seed=77, target_radius=5.0)
-    c2 = RtContext(0)
+    c2 = RtContext(0, variant="alt")      # (the quad kernel of the last step is in the alt build only)
     try:
         c2.set_param("blas_builder", 1)   # (the default)
         sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 0, 3, 2, sky=scenes.synthetic_skybox(64), ctx=c2, time_param=0.4)
@@ -966,7 +986,7 @@ def test_row_n4_mtl_materials_and_instance_types(ctx):
     the reference's two-way switch, materials with their own Ni and an illum-style forced type — all against the oracle;
     (c) removing table and types gives the reference's frame again, bit for bit."""
     from vulkan_raytracing_amd.api import MATERIAL_TYPE_OF_INSTANCE
-    c2 = RtContext(0)
+    c2 = RtContext(0, variant="alt")      # (step (b) also runs the alternative traversal kernels, which the product library does not hold)
     try:
         inst = [host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)]
         u = host.default_uniforms(max_bounce_count=2, samples_per_pixel=2, center_object_type=0, orbiting_object_type=0)
@@ -1319,6 +1339,48 @@ def test_entry_points_are_result_identical(ctx):
     both(256, 256)
 
 
+def test_entry_records_keep_the_far_flag_of_the_instance_they_enter(ctx):
+    """a primary ray that starts from an entry record which names an instance is moved into that instance's
+    object space at refill; whether it is FAR there (kernels.hip quant_far) must be decided against the MESH's quantisation, not
+    against the TLAS's.  A small mesh (the cube: 3e-5 units per quantum) inside a large TLAS (a second instance 3000 units away
+    makes the TLAS quantum 0.05), seen through a long lens from 50 to 20 000 mesh extents away — far in object space, not far in
+    world space: frames and ray counts with entry records equal the frames without them and the oracle's."""
+    cube = os.path.join(RES, "cube.obj")
+    eye = np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32)
+    for scale in (1.0, 0.01):       # (an instance scale of 0.01 multiplies every object-space distance by 100)
+        small = eye.copy(); small[0] = small[5] = small[10] = scale
+        small[3], small[7], small[11] = 0.3, -0.2, 0.1
+        away = eye.copy(); away[3], away[7], away[11] = 3000.0, 40.0, -2500.0
+        inst = [host.make_instance(small, 0, 0), host.make_instance(away, 1, 1)]
+        u = host.default_uniforms(max_bounce_count=1, samples_per_pixel=2, center_object_type=0, orbiting_object_type=1)
+        sp = scenes.ScenePair([cube, cube], inst, u, sky=scenes.synthetic_skybox(64), ctx=ctx)
+        base_u = sp.uniforms.copy()
+        try:
+            for dist, off in ((100.0, (0.0, 0.0, 1.0)), (400.0, (0.6, 0.3, 0.74)), (2500.0, (1.0, 0.002, 0.001)), (9000.0, (0.001, 1.0, 0.003)), (40000.0 if scale < 1.0 else 7000.0, (0.7, 0.0, 0.7))):
+                dirn = np.asarray(off, np.float64); dirn /= np.linalg.norm(dirn)
+                pos = np.array([0.3, -0.2, 0.1]) + dirn * dist * scale
+                fwd = -dirn
+                right = np.cross(fwd, [0.0, 1.0, 0.0] if abs(fwd[1]) < 0.9 else [1.0, 0.0, 0.0]); right /= np.linalg.norm(right)
+                up = np.cross(right, fwd)
+                uu = base_u.copy()
+                uu[0]["position"][:3] = pos
+                uu[0]["right"][:3] = right; uu[0]["up"][:3] = up
+                uu[0]["forward"][:3] = fwd * (dist / 4.0)       # long lens: the cube fills a good part of the frame
+                sp.set_uniforms(uu)
+                out = {}
+                for on in (1, 0):
+                    ctx.set_param("entry_points", on)
+                    img, st = ctx.trace(136, 104)
+                    out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow))
+                ctx.set_param("entry_points", 1)
+                assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1], (scale, dist)
+                ref, rc = sp.orc.render(136, 104)
+                check_image(out[1][0], ref)
+                assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2])) and out[1][1][2] > 500, (scale, dist, out[1][1])
+        finally:
+            ctx.set_param("entry_points", 1)
+
+
 def test_kept_shadow_entry_records_follow_the_light_and_the_instances(ctx):
     """rt_set_param "shadow_entry" 2 (the default): the records of the cube around the light depend on the light, the instances and the
     trees only, so they are KEPT while those stand still — built in a context's first frame and in the second consecutive frame with a new
@@ -1635,13 +1697,14 @@ def test_far_origins_up_to_the_pipelines_tmax_and_beyond(ctx):
     assert (st.rays_primary, st.rays_secondary, st.rays_shadow) == (int(rc[0]), int(rc[1]), int(rc[2])) and st.rays_secondary > 100
 
 
-def test_packet_kernel_is_result_identical(ctx):
+def test_packet_kernel_is_result_identical(ctx_alt):
     """k_packet (rt_set_param "packet_trace": one wavefront walks a 64-ray chunk together — wave-uniform stack, scalar node and
     triangle loads, every lane tests every visited node) is an alternative traversal kernel for the primary and the shadow rays,
     off by default because it measured slower.  A lane tests candidates its own ray would never have reached, so it only works
     because results do not depend on the set or order of candidates tested: frames and ray counts equal the one-lane-per-ray
     kernels', with and without entry records, for the shadow-ray records too, and record-level rays (incoherent: the worst case
-    for a packet) equal the oracle's brute force, closest hit and any hit."""
+    for a packet) equal the oracle's brute force, closest hit and any hit.  (librt_mi355x_alt.so: not in the product library.)"""
+    ctx = ctx_alt
     arm, _ = host.armadillo_path(RES)
     sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 2, 0, 4, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
     W, H = 328, 203

@@ -57,6 +57,47 @@ def test_multi_gpu_library_exports_every_declared_symbol():
         assert b"no HIP device" in L.rtm_last_error(None) or b"HIP" in L.rtm_last_error(None)
 
 
+def test_shipped_traversal_kernels_keep_their_register_budget():
+    """the traversal kernels sit exactly on the register budget of 5 waves per SIMD (what the LDS admits), so a
+    neutral-looking edit can push them into scratch or down to 4 waves.  `make resource-usage` (hipcc -Rpass-analysis=kernel-
+    resource-usage, a cross-compile: no GPU) reports every kernel of the product TU; the instantiations the BASELINE frames launch
+    — k_trace<.., FAR = false> for the closest-hit and the shadow rays, with and without entry records, and the tile kernels — must
+    keep 5 waves per SIMD with no scratch and no spills; the far-ray and record-level instantiations 4 waves at least, k_tail
+    (few rays, shading fused in) 3 — rt::tail_grid sizes its grid from the occupancy query anyway.
+    The product TU must also not contain the alternatives that measured slower (k_packet, k_trace4, 4-ary records)."""
+    out = subprocess.run(["make", "-C", ROOT, "resource-usage"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, check=True).stdout
+    kernels = {}
+    cur = None
+    for line in out.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+) \[-Rpass", line)
+        if m and cur is not None:
+            cur[m.group(1).strip()] = m.group(2)
+    names = "\n".join(kernels)
+    assert "k_packet" not in names and "k_trace4" not in names, "alternative kernels in the product TU"
+    # k_trace<MODE, ANY, WIDE, ENTRY, FAR>: _ZN2rt7k_traceILi<MODE>ELb<ANY>ELb<WIDE>ELb<ENTRY>ELb<FAR>EEEvNS_9TraceArgsE
+    hot, other = [], []
+    for name, r in kernels.items():
+        m = re.match(r"_ZN2rt7k_traceILi(\d)ELb(\d)ELb(\d)ELb(\d)ELb(\d)EEE", name)
+        if m:
+            mode, _, wide, _, far = (int(x) for x in m.groups())
+            assert wide == 0, name
+            (hot if (far == 0 and mode != 2) else other).append((name, r))
+        elif re.match(r"_ZN2rt(12k_trace_tile|6k_tail)I", name) and "Lb1E" not in name.split("I", 1)[1][:6]:
+            (hot if "k_trace_tile" in name else other).append((name, r))
+    assert len(hot) >= 4, names
+    for name, r in hot:
+        assert int(r["Occupancy"]) >= 5 and int(r["ScratchSize"]) == 0 and int(r["VGPRs Spill"]) == 0 and int(r["SGPRs Spill"]) == 0, (name, r)
+    for name, r in other:
+        if "k_tail" in name:
+            assert int(r["Occupancy"]) >= 3, (name, r)
+        else:
+            assert int(r["Occupancy"]) >= 4 and int(r["ScratchSize"]) <= 32, (name, r)
+
+
 def test_no_gpu_means_loud_failure():
     """Without a HIP device the product refuses to run (no CPU fallback)."""
     import torch

@@ -25,7 +25,7 @@ def _load(name, make_target):
         raise NativeLibraryError("cannot load %s: %s" % (path, e))
 
 
-def load_rt():
+def load_rt(variant=None):
     # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7).
     # Two HIP/HSA runtimes cannot share one process, so when torch is installed it is imported FIRST:
     # librt_mi355x.so's DT_NEEDED libamdhip64.so.7 then binds to the copy torch already loaded and the
@@ -35,7 +35,9 @@ def load_rt():
     except ImportError:
         pass
     # RT_LIB_VARIANT=<suffix> loads librt_mi355x_<suffix>.so (kernel experiments built next to the product)
-    suffix = os.environ.get("RT_LIB_VARIANT")
+    suffix = variant or os.environ.get("RT_LIB_VARIANT")
+    if suffix == "alt":
+        return _load("librt_mi355x_alt.so", "alt")
     if suffix:
         return ctypes.CDLL(os.path.join(PKG_DIR, "librt_mi355x_%s.so" % suffix))
     return _load("librt_mi355x.so", "vulkan_raytracing_amd/librt_mi355x.so")

@@ -40,13 +40,14 @@ EXPORTS = ["rt_create", "rt_create_frame_slot", "rt_destroy", "rt_upload_geometr
            "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_assemble_shards", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
            "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_debug_sizing", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
-_LIB = None
+_LIBS = {}
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        L = _native.load_rt()
+def lib(variant=None):
+    """librt_mi355x.so, or librt_mi355x_<variant>.so (variant "alt": the build that also holds the traversal kernels which
+    measured slower — k_packet, the quad/BVH4 kernel, 4-ary records; `make alt`).  RT_LIB_VARIANT names the default."""
+    if variant not in _LIBS:
+        L = _native.load_rt(variant)
         vp = C.c_void_p
         L.rt_create.argtypes = [C.POINTER(vp), C.c_int]
         L.rt_create_frame_slot.argtypes = [vp, C.POINTER(vp)]
@@ -77,8 +78,8 @@ def lib():
         L.rt_last_error.restype = C.c_char_p
         L.rt_device_info.argtypes = [vp]
         L.rt_device_info.restype = C.c_char_p
-        _LIB = L
-    return _LIB
+        _LIBS[variant] = L
+    return _LIBS[variant]
 
 
 class RtError(RuntimeError):
@@ -97,8 +98,8 @@ def _p(a):
 class RtContext:
     """One context = one GPU (rt_create).  Methods map 1:1 onto the C ABI."""
 
-    def __init__(self, device=0, _parent=None):
-        self.L = lib()
+    def __init__(self, device=0, _parent=None, variant=None):
+        self.L = _parent.L if _parent is not None else lib(variant)
         h = C.c_void_p()
         if _parent is not None:
             rc = self.L.rt_create_frame_slot(_parent.h, C.byref(h))

@@ -887,11 +887,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
   __shared__ uint32_t s_ent[(ENTRY && MODE == MODE_SHADOW) ? 4 : 1][64];   // entry record of every ray of the current chunk
-  // BVH nodes staged through LDS: the first n_hot entries of the node array are the top levels of every BLAS (breadth-first
-  // over all meshes, rt_api link_blas) — the nodes nearly every ray visits.  A visit to one of them is two ds_read_b128
-  // instead of two divergent 16-byte requests to the CU's vector-memory address unit, which is what bounds this kernel
-  // (about one such lane request per cycle and CU: profiles/r02_*).
-  __shared__ uint4 s_hot[(WIDE || HOT_NODES == 0) ? 1 : HOT_NODES * 2];
   // Instance records staged through LDS: what "enter the instance" reads (world->object rows, dequantisation, root, mask)
   // for the first LDS_INSTANCES instances, 80 bytes each.  That phase runs for a quarter of the lanes at a time and was
   // spending ~1200 cycles per pass on the global-memory latency of these few, shared records.
@@ -907,11 +902,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
     if (want < a.min_blocks) want = a.min_blocks;
     if (blockIdx.x >= want) return;
-  }
-  const uint32_t n_hot = (WIDE || HOT_NODES == 0) ? 0u : a.sc.n_hot;
-  if (!WIDE && HOT_NODES != 0) {
-    const uint4* src = reinterpret_cast<const uint4*>(a.sc.blas_nodes);
-    for (uint32_t i = threadIdx.x; i < n_hot * 2u; i += 256u) s_hot[i] = src[i];
   }
   const int n_lds_inst = a.sc.n_inst < LDS_INSTANCES ? a.sc.n_inst : LDS_INSTANCES;
   if ((int)threadIdx.x < n_lds_inst) {
@@ -993,9 +983,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   // BLAS nodes, then the TLAS nodes (WIDE: the 64-byte 4-ary records with the same numbering)
   const char* const node_bytes = WIDE ? reinterpret_cast<const char*>(a.sc.wide_nodes) : reinterpret_cast<const char*>(a.sc.blas_nodes);
 
-#if defined(RT_EXP_EXTRA_LOADS) || defined(RT_EXP_EXTRA_VALU)
-  uint32_t exp_acc = 0; float exp_f[4] = {0.5f, 0.25f, 0.125f, 0.75f};
-#endif
   auto push = [&](int v) {
     if (sp < STACK2_LDS) stk[sp * 64] = v;
     else *reinterpret_cast<volatile int32_t*>(ovf + (sp - STACK2_LDS)) = v;
@@ -1085,7 +1072,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
               cur = cur_new;
               __builtin_amdgcn_sched_barrier(0);   // the record's words are on the stack before the instance record is fetched (register peak of the kernel)
               if (ia != ENTRY_NO_INST) { int root; uint32_t imask; to_instance((int)ia, root, imask); cur_inst = (int)ia; }   // (k_entry never names an invisible instance)
-              else quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
+              else { quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale); }   // (to_instance set `far` against the MESH's quantisation: it must survive)
             }
           } else {
             quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
@@ -1144,12 +1131,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         return;
       }
       if (cur >= 0) {   // idle lanes hold REF_DONE
-        uint4 Q0, Q1;
-        if ((uint32_t)cur < n_hot) { Q0 = s_hot[2 * cur]; Q1 = s_hot[2 * cur + 1]; }
-        else {
-          const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
-          Q0 = np[0]; Q1 = np[1];
-        }
+        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));   // 32-byte node: two requests
+        const uint4 Q0 = np[0], Q1 = np[1];
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
         if (COUNT) cnt_nodes++;
         float t0, t1;
@@ -1211,23 +1194,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
 #else
     auto fast_step = [&]() {
       if (cur >= 0) {
-        uint4 Q0, Q1;
-        if ((uint32_t)cur < n_hot) { Q0 = s_hot[2 * cur]; Q1 = s_hot[2 * cur + 1]; }
-        else {
-          const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));
-          Q0 = np[0]; Q1 = np[1];
-        }
-#ifdef RT_EXP_EXTRA_LOADS   // sensitivity build: every visit also fetches the neighbouring node (results unused but kept alive)
-        {
-          const uint4* xp = reinterpret_cast<const uint4*>(node_bytes + (((uint32_t)cur ^ 1u) << 5));
-          const uint4 X0 = xp[0], X1 = xp[1];
-          exp_acc ^= X0.x ^ X0.w ^ X1.y ^ X1.w;
-        }
-#endif
-#ifdef RT_EXP_EXTRA_VALU    // sensitivity build: RT_EXP_EXTRA_VALU independent fmas per visit
-#pragma unroll
-        for (int e = 0; e < RT_EXP_EXTRA_VALU; e++) asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(exp_f[e & 3]));
-#endif
+        const uint4* np = reinterpret_cast<const uint4*>(node_bytes + ((uint32_t)cur << 5));
+        const uint4 Q0 = np[0], Q1 = np[1];
         // volatile: the read has to be issued here, under the node fetch, not sunk into a branch after the box tests
         const int top = stk_lds[(sp - 1) * 64];
         const int2 ch = make_int2((int)Q1.z, (int)Q1.w);
@@ -1244,22 +1212,16 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
       }
     };
 #endif
-#ifdef RT_EXP_PHASE_DIAG   // experiment: diag = (outer passes, cycles inside the interior loop, wave cycles)
-    const uint64_t ph_t0 = COUNT ? __builtin_readcyclecounter() : 0;
-#endif
     constexpr int UNROLL = WIDE ? RT_WIDE_UNROLL : RT_INTERIOR_UNROLL;
     for (;;) {
       const uint32_t n_int = (uint32_t)__builtin_popcountll(__ballot(cur >= 0));
       if (n_int == 0 || n_int < keep_going) break;
-#if !defined(RT_EXP_PHASE_DIAG) && !defined(RT_EXP_DEEP_DIAG) && !defined(RT_EXP_PHASE_SEL) && !defined(RT_EXP_VISIT_STAMPS)
+#if !defined(RT_EXP_PHASE_SEL) && !defined(RT_EXP_VISIT_STAMPS)
       if (COUNT && lane == 0) { diag_iters++; diag_busy += n_int; }
 #endif
       // fast visits need every stack they touch inside the LDS rows: sp - 1 >= 0 always holds for a live ray, and
       // UNROLL pushes must fit below row STACK2_LDS
       const bool deep = cur >= 0 && (sp + UNROLL > STACK2_LDS || far);   // far rays: the generic visit has the widened slab test
-#ifdef RT_EXP_DEEP_DIAG   // experiment: diag = (interior loop votes, votes that took the generic deep-stack path, wave cycles)
-      if (COUNT && lane == 0) { diag_iters++; diag_busy += __ballot(deep) != 0 ? 1u : 0u; }
-#endif
       if (!WIDE && __ballot(deep) == 0) {
 #pragma unroll
         for (int r = 0; r < UNROLL; r++) fast_step();
@@ -1268,9 +1230,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
         for (int r = 0; r < UNROLL; r++) interior_step();
       }
     }
-#ifdef RT_EXP_PHASE_DIAG
-    if (COUNT && lane == 0) { diag_iters++; diag_busy += __builtin_readcyclecounter() - ph_t0; }
-#endif
 
     // ---- (C) the rarer bodies, each run once for all lanes that wait at them.  They are chained (leaf, then
     // leave-instance, then enter-instance) so that a lane can finish a leaf, leave its instance and enter the
@@ -1352,9 +1311,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     }
     PH_END(4)
   }
-#if defined(RT_EXP_EXTRA_LOADS) || defined(RT_EXP_EXTRA_VALU)
-  if (exp_acc == 0x9E3779B9u && exp_f[0] + exp_f[1] + exp_f[2] + exp_f[3] == 12345.0f) a.counters[CNT_FAULT] = 2u;   // keeps the extra work alive
-#endif
   if (COUNT) {
     for (int off = 32; off > 0; off >>= 1) {
       cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
@@ -1380,519 +1336,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PE
 template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true>
 __global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY, FAR>(a); }
 
-// ------------------------------------------------------------------------------------------------
-// k_packet: PACKET traversal — one wavefront walks one 64-ray chunk TOGETHER.  The rays of a chunk are coherent by
-// construction: primary rays of one 8x8 tile (k_raygen appends a tile's four samples in one run), shadow rays of neighbouring
-// hit points towards one light.  So the wave keeps ONE stack (a wave-uniform stack pointer in an SGPR, the entries in the lanes
-// of one VGPR: v_writelane / v_readlane), visits ONE node at a time, and every lane tests ITS ray against the node's two child
-// boxes; the wave descends where any lane wants to (near child by majority vote) and skips what no lane can hit.  What this
-// buys over one lane per ray (trace_body):
-//   * no divergence: every VALU instruction works for 64 rays, there are no phases and no waiting for the slowest lane's leaf;
-//   * node, triangle and instance records are wave-uniform: they come through the SCALAR cache (s_load_dwordx8 / x4) into
-//     SGPRs — one request per wave and visit instead of 64 lane requests to the vector memory path;
-//   * no LDS at all and ~60 VGPRs: eight waves per SIMD hide the scalar-load latency.
-// A lane tests nodes its own ray would never have reached (the union of the chunk's walks is visited), so results must not
-// depend on the order or the set of candidates tested — and they do not: the closest hit is the minimum over ALL accepted
-// candidates with the (instance, primitive) tie rule, an any-hit query only asks whether one exists.
-// Entry records (k_entry) start the walk of the lanes that share a tile; a chunk that straddles tiles is walked tile by tile.
-typedef uint32_t u32x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(4))) const u32x8 k_u32x8;   // constant address space: a uniform address loads through the scalar cache
-typedef __attribute__((address_space(4))) const u32x4 k_u32x4;
-__device__ __forceinline__ u32x8 sload8(const void* p) { return *(const k_u32x8*)(uintptr_t)p; }
-__device__ __forceinline__ u32x4 sload4(const void* p) { return *(const k_u32x4*)(uintptr_t)p; }
-__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
-// lane `sel` (wave-uniform) of `reg` := the wave-uniform value v
-__device__ __forceinline__ int lane_write(int reg, int v, int sel) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  // (v_writelane takes one SGPR besides the lane select in M0 — two SGPRs would exceed gfx9's constant bus; M0 is saved and restored)
-  int keep;
-  asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(reg), "=&s"(keep) : "s"(v), "s"(sel));
+#ifdef RT_ALT_KERNELS
+#include "kernels_alt.inc"   // k_packet, k_trace4: alternatives measured slower, only in librt_mi355x_alt.so
 #endif
-  return reg;
-}
-
-template <int MODE, bool ANY, bool COUNT, bool ENTRY>
-__global__ __launch_bounds__(256) void k_packet(TraceArgs a) {
-  {
-    uint32_t total = 0;
-#pragma unroll
-    for (int t = 0; t < N_SHARDS; t++) total += ld_cursor(a.tails + t * CNT_STRIDE);
-    uint32_t want = (total + 256u * a.rays_per_lane - 1u) / (256u * a.rays_per_lane);
-    want = (want + (N_SHARDS - 1)) & ~(uint32_t)(N_SHARDS - 1);
-    if (want < a.min_blocks) want = a.min_blocks;
-    if (blockIdx.x >= want) return;
-  }
-  const uint32_t lane = threadIdx.x & 63u;
-  uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
-  uint64_t cnt_nodes = 0, cnt_tris = 0, wave_nodes = 0, wave_tris = 0;   // per lane: what its own ray enters; per wave (lane 0): what the packet visits
-  const uint64_t diag_t0 = COUNT ? __builtin_readcyclecounter() : 0;
-  const char* const node_bytes = reinterpret_cast<const char*>(a.sc.blas_nodes);
-  const char* const inst_bytes = reinterpret_cast<const char*>(a.sc.inst);
-  for (;;) {
-    // ---- next 64-ray chunk of the sharded queues (wave-uniform)
-    uint32_t base = 0, count = 0;
-    while (tried < (uint32_t)N_SHARDS) {
-      const uint32_t size = ld_cursor(a.tails + shard * CNT_STRIDE);
-      uint32_t off = 0;
-      if (lane == 0 && size) off = atomicAdd(a.work + shard * CNT_STRIDE, 64u);
-      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
-      if (size && off < size) { base = shard * a.shard_cap + off; count = (size - off) < 64u ? (size - off) : 64u; break; }
-      shard = (shard + 1u) & (N_SHARDS - 1); tried++;
-    }
-    if (count == 0) break;
-    const bool on = lane < count;
-    const uint32_t q = base + lane;
-    float4 ro = make_float4(0, 0, 0, 0), rd = make_float4(0, 0, 1, 0);
-    if (on) { ro = a.ray_o[q]; rd = a.ray_d[q]; }
-    const float tmin = MODE == MODE_RAW ? ro.w : a.tmin;
-    const float tmax = MODE == MODE_RAW ? rd.w : ((ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : ro.w);   // (ENTRY closest: o.w carries the tile)
-    const F3 wo = mk3(ro.x, ro.y, ro.z), wd = mk3(rd.x, rd.y, rd.z);
-    float best_t = tmax, best_u = 0.f, best_v = 0.f;
-    int best_prim = -1, best_inst = -1;
-    uint32_t ent = ENTRY_FROM_ROOT;
-    if (ENTRY) ent = MODE == MODE_SHADOW ? (on ? a.sh_e[q] : ENTRY_FROM_ROOT) : __float_as_uint(ro.w);
-
-    uint64_t todo = __ballot(on);
-    while (todo != 0ull) {
-      // ---- the lanes that share an entry record (without records: everybody) walk together
-      uint64_t grp = todo;
-      uint32_t e0 = ENTRY_FROM_ROOT;
-      if (ENTRY) {
-        e0 = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)__builtin_ctzll(todo));
-        grp = __ballot(on && ((todo >> lane) & 1ull) != 0ull && ent == e0);
-      }
-      todo &= ~grp;
-      bool alive = ((grp >> lane) & 1ull) != 0ull;   // any-hit: cleared once the lane has its hit
-
-      F3 co = wo, cd = wd, qs, qb; uint3 rot;
-      quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
-      bool far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
-      int sp = 0, stk0 = 0, stk1 = 0;   // wave stack: entry e lives in lane e of stk0 (e < 64) / lane e - 64 of stk1
-      auto push = [&](int v) {
-        if (sp < 64) stk0 = lane_write(stk0, v, sp); else stk1 = lane_write(stk1, v, sp - 64);
-        sp++;
-      };
-      auto pop = [&]() -> int {
-        if (sp == 0) return REF_DONE;
-        sp--;
-        return sp < 64 ? __builtin_amdgcn_readlane(stk0, sp) : __builtin_amdgcn_readlane(stk1, sp - 64);
-      };
-      int cur = a.sc.tlas_root, cur_inst = -1;
-      // ray -> object space of instance ii (all lanes, uniform instance); returns false for an instance the ray mask cannot see
-      auto enter = [&](int ii, int& root) -> bool {
-        const char* ip = inst_bytes + (size_t)ii * sizeof(InstanceDev);
-        const u32x8 A = sload8(ip + 96);        // blas_root, mask, custom_index, first_float, first_index, blas_root4, q_lo[0], q_lo[1]
-        if ((A[1] & 0xFFu) == 0u) return false;
-        const u32x4 B = sload4(ip + 128);       // q_lo[2], q_scale[0..2]
-        const u32x8 M0 = sload8(ip);            // w2o rows 0, 1
-        const u32x4 M1 = sload4(ip + 32);       // w2o row 2
-        const float m[12] = {u2f(M0[0]), u2f(M0[1]), u2f(M0[2]), u2f(M0[3]), u2f(M0[4]), u2f(M0[5]), u2f(M0[6]), u2f(M0[7]), u2f(M1[0]), u2f(M1[1]), u2f(M1[2]), u2f(M1[3])};
-        co = xform_point(m, wo); cd = xform_vec(m, wd);
-        const float qlo3[3] = {u2f(A[6]), u2f(A[7]), u2f(B[0])}, qsc3[3] = {u2f(B[1]), u2f(B[2]), u2f(B[3])};
-        quant_space(co, cd, qlo3, qsc3, qs, qb, rot);
-        far = quant_far_o(co, qlo3, qsc3);
-        root = (int)A[0];
-        return true;
-      };
-      if (ENTRY && e0 != ENTRY_FROM_ROOT) {
-        const u32x8 R = sload8(a.entry + (e0 & ~ENTRY_REVERSE));
-        const uint32_t hdr = R[0];
-        if (hdr == ENTRY_EMPTY) continue;   // nothing a ray of this tile can hit
-        const uint32_t nw = hdr & 15u, n_rm = (hdr >> 4) & 15u, ia = hdr >> 8;
-        const int w[6] = {(int)R[2], (int)R[3], (int)R[4], (int)R[5], (int)R[6], (int)R[7]};
-        if ((e0 & ENTRY_REVERSE) != 0u && nw > n_rm) {
-          // the instance's subtrees in the opposite order: [words below] [old first node] [the rest, top to bottom]; walk starts at the bottom one
-#pragma unroll
-          for (uint32_t k = 0; k < 6u; k++) if (k < n_rm) push(w[k]);
-          push((int)R[1]);
-#pragma unroll
-          for (int k = 5; k >= 1; k--) if ((uint32_t)k < nw && (uint32_t)k > n_rm) push(w[k]);
-          cur = n_rm == 0u ? w[0] : n_rm == 1u ? w[1] : n_rm == 2u ? w[2] : n_rm == 3u ? w[3] : n_rm == 4u ? w[4] : w[5];
-        } else {
-#pragma unroll
-          for (uint32_t k = 0; k < 6u; k++) if (k < nw) push(w[k]);
-          cur = (int)R[1];
-        }
-        if (ia != ENTRY_NO_INST) { int root; enter((int)ia, root); cur_inst = (int)ia; }   // (k_entry never names an invisible instance; the record holds the marker)
-      }
-
-      for (;;) {
-        if (cur >= 0) {
-          // ---- interior node: one scalar fetch, every lane tests both children
-          const u32x8 Q = sload8(node_bytes + ((size_t)(uint32_t)cur << 5));
-          const int c0 = (int)Q[6], c1 = (int)Q[7];
-          const bool any_far = __ballot(alive && far) != 0ull;
-          float t0 = 0.f, t1 = 0.f;
-          bool h0, h1;
-          if (any_far && cur_inst < 0) {   // far rays in world space: the TLAS does not cull (see quant_far)
-            h0 = alive && (Q[0] & 0xFFFFu) <= (Q[0] >> 16); h1 = alive && (Q[3] & 0xFFFFu) <= (Q[3] >> 16);
-          } else if (any_far) {
-            h0 = alive && slab_q_far(Q[0], Q[1], Q[2], qs, qb, rot, tmin, best_t, t0);
-            h1 = alive && slab_q_far(Q[3], Q[4], Q[5], qs, qb, rot, tmin, best_t, t1);
-          } else {
-            h0 = alive && slab_q(Q[0], Q[1], Q[2], qs, qb, rot, tmin, best_t, t0);
-            h1 = alive && slab_q(Q[3], Q[4], Q[5], qs, qb, rot, tmin, best_t, t1);
-          }
-          const uint64_t m0 = __ballot(h0), m1 = __ballot(h1);
-          if (COUNT && lane == 0) wave_nodes++;
-          if (COUNT) {   // a lane "visits" the children its own ray enters (what one lane per ray would have visited)
-            if (h0) { if (c0 >= 0 || cur_inst < 0) cnt_nodes++; else cnt_tris += ((uint32_t)(~c0) & 7u) + 1u; }
-            if (h1) { if (c1 >= 0 || cur_inst < 0) cnt_nodes++; else cnt_tris += ((uint32_t)(~c1) & 7u) + 1u; }
-          }
-          if (m0 != 0ull && m1 != 0ull) {
-            const uint64_t pref1 = __ballot(h1 && (!h0 || t1 < t0));   // lanes that would take child 1 first
-            const bool first1 = 2 * __builtin_popcountll(pref1) > __builtin_popcountll(m0 | m1);
-            push(first1 ? c0 : c1);
-            cur = first1 ? c1 : c0;
-          } else if (m0 != 0ull) cur = c0;
-          else if (m1 != 0ull) cur = c1;
-          else cur = pop();
-        } else if (cur == REF_DONE) {
-          break;
-        } else if (cur == REF_MARK) {
-          // leave the instance: world space again
-          cur_inst = -1;
-          co = wo; cd = wd;
-          quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot);
-          far = quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
-          cur = pop();
-        } else if (cur_inst < 0) {
-          // TLAS leaf: enter the instance
-          const int ii = ~cur;
-          int root = 0;
-          if (enter(ii, root)) { push(REF_MARK); cur_inst = ii; cur = root; }
-          else cur = pop();
-        } else {
-          // BLAS leaf: every lane tests the leaf's triangles
-          const uint32_t ref = (uint32_t)(~cur);
-          const uint32_t first = ref >> 3, n_tri = (ref & 7u) + 1u;
-          if (COUNT && lane == 0) wave_tris += n_tri;
-          for (uint32_t k = 0; k < n_tri; k++) {
-            const char* tp = reinterpret_cast<const char*>(a.sc.tris) + (size_t)(first + k) * 48u;
-            const u32x8 TA = sload8(tp);        // 32-byte aligned for even packets only: two x4 loads are always legal
-            const u32x4 TB = sload4(tp + 32);
-            const float4 T0 = make_float4(u2f(TA[0]), u2f(TA[1]), u2f(TA[2]), u2f(TA[3])), T1 = make_float4(u2f(TA[4]), u2f(TA[5]), u2f(TA[6]), u2f(TA[7]));
-            const float4 T2 = make_float4(u2f(TB[0]), u2f(TB[1]), u2f(TB[2]), u2f(TB[3]));
-            float tt, uu, vv;
-            if (alive && tri_test(T0, T1, T2, co, cd, tmin, (ANY ? best_t : tmax), tt, uu, vv)) {
-              if (ANY) { best_inst = cur_inst; best_t = tt; best_u = uu; best_v = vv; best_prim = (int)TB[1]; alive = false; }   // any hit ends this lane's ray (flags 13, src/shader.rgen:67)
-              else {
-                const int prim = (int)TB[1];
-                const bool better = (best_inst < 0) || (tt < best_t) ||
-                                    (tt == best_t && (cur_inst < best_inst || (cur_inst == best_inst && prim < best_prim)));
-                if (better) { best_t = tt; best_u = uu; best_v = vv; best_prim = prim; best_inst = cur_inst; }
-              }
-            }
-          }
-          if (ANY && __ballot(alive) == 0ull) break;   // every ray of the group has its hit
-          cur = pop();
-        }
-      }
-    }
-    // ---- results: one coalesced store per lane
-    if (on) {
-      if (MODE == MODE_CLOSEST) { st_stream(&a.hit_a[q], make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim))); st_stream(&a.hit_inst[q], best_inst); }
-      else if (MODE == MODE_SHADOW) {
-        // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
-        float cr = 0.08f, cg = 0.24f, cb = 0.08f;
-        if (best_inst < 0 || a.sc.n_materials != 0) {
-          const float4 shc = a.sh_c[q];
-          if (best_inst < 0) { cr = shc.x; cg = shc.y; cb = shc.z; }
-          else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); cr = amb.x; cg = amb.y; cb = amb.z; }
-        }
-        st_stream(&a.sample_color[__float_as_uint(rd.w)], make_float4(cr, cg, cb, 1.0f));
-      } else { HitRec h; h.t = best_t; h.u = best_u; h.v = best_v; h.prim = best_prim; h.inst = best_inst; a.raw_out[q] = h; }
-    }
-  }
-  if (COUNT) {
-    for (int off = 32; off > 0; off >>= 1) {
-      cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
-      cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
-    }
-    if (lane == 0) {
-      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
-      // diag = (nodes the packets visited, triangles the packets tested, wave cycles): wave-level work, against the per-ray counts above
-      const int dg = ANY ? CNT_DIAG_SH : CNT_DIAG;
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg), (unsigned long long)wave_nodes);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 2), (unsigned long long)wave_tris);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 4), (unsigned long long)(__builtin_readcyclecounter() - diag_t0));
-    }
-  }
-}
-
-// ---- variant 1: quad-cooperative traversal — FOUR LANES PER RAY over a BVH4, 16 rays per
-// 64-lane wavefront.
-//   * interior node (128 B, one cache line): lane k of the quad loads and tests child k (2 x dwordx4
-//     per lane, 4 consecutive 32-byte records per quad): one line look-up per ray and visit, and
-//     half as many dependent visits as the BVH2;
-//   * the four (hit, t_near) results are ranked inside the quad with DPP quad_perm moves — no LDS,
-//     no scalar loop; the nearest child becomes the next node, the others are written to the ray's
-//     LDS stack by their own lanes in far-to-near order;
-//   * leaf (<= 4 triangles): lane k runs Moller-Trumbore on triangle k, a quad-min picks the winner;
-//   * only 16 rays share a program counter, so incoherent rays lose far less to divergence;
-//   * persistent threads: each wave pulls 64-ray chunks from the sharded cursors, the chunk after
-//     next is already in flight into registers while the current one sits in LDS, and every quad
-//     that finishes a ray takes the next one from LDS at once (ballot + prefix rank) — no quad
-//     waits for its neighbours and no refill waits on HBM.
-// Control flow (cur, cur_inst, sp, need) is uniform within a quad, which keeps every DPP source lane
-// active.  Results are identical to k_trace: same triangle arithmetic, same tie rule.
-constexpr int QP_ROT1 = 0x39, QP_ROT2 = 0x4E, QP_ROT3 = 0x93, QP_SWAP1 = 0xB1, QP_SWAP2 = 0x4E;
-template <int CTRL> __device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
-  // every source lane of a quad_perm is active here (control flow is quad-uniform), so no `old` value is needed
-  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true);
-}
-__device__ __forceinline__ uint32_t quad_or(uint32_t v) { v |= dpp_u<QP_SWAP1>(v); v |= dpp_u<QP_SWAP2>(v); return v; }
-__device__ __forceinline__ float quad_minf(float v) {
-  v = fminf(v, __uint_as_float(dpp_u<QP_SWAP1>(__float_as_uint(v))));
-  v = fminf(v, __uint_as_float(dpp_u<QP_SWAP2>(__float_as_uint(v))));
-  return v;
-}
-__device__ __forceinline__ int quad_mini(int v) {
-  v = min(v, (int)dpp_u<QP_SWAP1>((uint32_t)v));
-  v = min(v, (int)dpp_u<QP_SWAP2>((uint32_t)v));
-  return v;
-}
-
-// Ray space of the quad kernel (float boxes, sub-mul slab test).  An fma form (t = plane/d - o/d) was measured
-// 45 % slower on the any-hit kernel, and packed v_pk_fma_f32 slower still (the file is built with -fno-slp-vectorize).
-struct RaySpace {
-  F3 id;   // 1/d
-};
-__device__ __forceinline__ RaySpace make_space(F3 o, F3 d) {
-  (void)o;
-  RaySpace r;
-  r.id = mk3(safe_rcp(d.x), safe_rcp(d.y), safe_rcp(d.z));
-  return r;
-}
-
-template <int MODE, bool ANY, bool COUNT>
-__global__ __launch_bounds__(256) void k_trace4(TraceArgs a) {
-  __shared__ int s_stack[4][STACK4_LDS][16];                      // [wave][entry][ray]
-  __shared__ float4 s_rays[4][MODE == MODE_SHADOW ? 3 : 2][64];   // current chunk of each wave
-  __shared__ float4 s_world[4][2][16];                            // world-space ray of each quad
-  __shared__ float4 s_out[4][64];                                 // finished results, flushed in bursts
-  __shared__ int2 s_outq[4][64];                                  // (queue slot | sample id, instance)
-  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-  const uint32_t sub = lane & 3u, ray = lane >> 2;
-  int(*stk)[16] = s_stack[wave];
-  const uint32_t KEY_MISS = 0xFFFFFFF0u;
-  const char* const node_bytes = reinterpret_cast<const char*>(a.sc.nodes4);   // BLAS nodes then TLAS nodes: one base
-  const uint32_t lane_off = sub * 32u, quad_shift = lane & ~3u;
-  int* const stk_ray = &stk[0][ray];
-  uint64_t cnt_nodes = 0, cnt_tris = 0;
-
-  // ---- work distribution (wave-uniform): prefetched chunk in registers, current chunk in LDS
-  uint32_t shard = blockIdx.x & (N_SHARDS - 1), tried = 0;
-  uint32_t pf_base = 0, pf_count = 0;
-  float4 pf_o = make_float4(0, 0, 0, 0), pf_d = pf_o, pf_c = pf_o;
-  uint32_t chunk_base = 0, chunk_count = 0, chunk_pos = 0;
-  auto prefetch = [&]() {
-    pf_count = 0;
-    while (tried < (uint32_t)N_SHARDS) {
-      const uint32_t size = a.tails[shard * CNT_STRIDE];
-      uint32_t off = 0;
-      if (lane == 0 && size) off = atomicAdd(a.work + shard * CNT_STRIDE, 64u);
-      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
-      if (size && off < size) { pf_base = shard * a.shard_cap + off; pf_count = (size - off) < 64u ? (size - off) : 64u; break; }
-      shard = (shard + 1u) & (N_SHARDS - 1); tried++;
-    }
-    if (lane < pf_count) {
-      pf_o = a.ray_o[pf_base + lane]; pf_d = a.ray_d[pf_base + lane];
-      if (MODE == MODE_SHADOW) pf_c = a.sh_c[pf_base + lane];
-    }
-  };
-  auto promote = [&]() {
-    s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
-    if (MODE == MODE_SHADOW) s_rays[wave][2][lane] = pf_c;
-    chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
-    prefetch();
-  };
-  prefetch();
-  promote();
-
-  // ---- per-quad ray state (uniform within a quad)
-  bool need = true;
-  uint32_t q = 0, sid = 0;
-  float tmin = 0.f, tmax = 0.f;
-  F3 co = mk3(0, 0, 0), cd = mk3(0, 0, 1);
-  RaySpace rs = make_space(co, cd);
-  float4 shc = make_float4(0, 0, 0, 0);
-  float best_t = 0.f, best_u = 0.f, best_v = 0.f;
-  int best_prim = -1, best_inst = -1, cur_inst = -1, sp = 0, cur = REF_DONE;
-  uint64_t diag_iters = 0, diag_busy = 0;
-  const uint64_t diag_t0 = COUNT ? __builtin_readcyclecounter() : 0;
-  // Results are staged in LDS and written out in bursts of >= 48: stores share the wave's in-order
-  // vmcnt with the node loads, so a store per finished ray would stall the next node fetch every time.
-  uint32_t out_count = 0;
-  auto flush = [&]() {
-    if (lane < out_count) {
-      const float4 r = s_out[wave][lane];
-      const int2 k = s_outq[wave][lane];
-      if (MODE == MODE_CLOSEST) { st_stream(&a.hit_a[k.x], r); st_stream(&a.hit_inst[k.x], k.y); }
-      else if (MODE == MODE_SHADOW) st_stream(&a.sample_color[k.x], r);
-      else { HitRec h; h.t = r.x; h.u = r.y; h.v = r.z; h.prim = (int)__float_as_uint(r.w); h.inst = k.y; a.raw_out[k.x] = h; }
-    }
-    out_count = 0;
-  };
-
-  for (;;) {
-    // ---- (A) refill: quads without a ray take the next rays of the LDS chunk
-    const uint64_t need_mask = __ballot(need);
-    if (need_mask != 0) {
-      if (chunk_pos == chunk_count && pf_count > 0) promote();
-      if (chunk_pos < chunk_count) {
-        const uint32_t rank = prefix_rank(need_mask) >> 2;   // needing quads before this one
-        const uint32_t want = (uint32_t)__builtin_popcountll(need_mask) >> 2;
-        const uint32_t avail = chunk_count - chunk_pos;
-        if (need && rank < avail) {
-          const uint32_t ci = chunk_pos + rank;
-          q = chunk_base + ci;
-          const float4 ro = s_rays[wave][0][ci], rd = s_rays[wave][1][ci];
-          if (MODE == MODE_SHADOW) shc = s_rays[wave][2][ci];
-          if (MODE == MODE_RAW) { tmin = ro.w; tmax = rd.w; }
-          else { tmin = a.tmin; tmax = ro.w; sid = __float_as_uint(rd.w); }
-          if (sub == 0) { s_world[wave][0][ray] = ro; s_world[wave][1][ray] = rd; }
-          co = mk3(ro.x, ro.y, ro.z); cd = mk3(rd.x, rd.y, rd.z);
-          rs = make_space(co, cd);
-          best_t = tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
-          cur_inst = -1;
-          stk[0][ray] = REF_DONE; sp = 1;
-          cur = a.sc.tlas_root4;
-          need = false;
-        }
-        chunk_pos += want < avail ? want : avail;
-      } else if (need_mask == ~0ull) { flush(); break; }   // queue drained and every quad idle
-    }
-    do {   // phases B and C run only for quads that hold a ray; phase D below is wave-uniform
-    if (need) break;
-
-    // ---- (B) interior steps: stay in this loop while the quad's node is interior
-    while (cur >= 0) {
-      const uint32_t off = ((uint32_t)cur << 7) + lane_off;        // 128-byte node, 32-byte child record
-      const float4* cp = reinterpret_cast<const float4*>(node_bytes + off);
-      const float4 A = cp[0], B = cp[1];
-      if (COUNT) { if (sub == 0) cnt_nodes++; if (lane == (uint32_t)__builtin_ctzll(__ballot(true))) diag_iters++; }
-      float tn;
-      // sub-mul form: measured faster than the fma form on the any-hit kernel (0.76 vs 1.13 ms) and exact at o == plane
-      const bool hit = slab(A.x, A.y, A.z, A.w, B.x, B.y, co, rs.id, tmin, best_t, tn);
-      const int ref = (int)__float_as_uint(B.z);
-      // hit children of this quad: 4 bits of the wave ballot
-      const uint32_t qbits = (uint32_t)(__ballot(hit) >> quad_shift) & 0xFu;
-      const int nh = __builtin_popcount(qbits);
-      const uint32_t key = hit ? ((__float_as_uint(tn) & ~3u) | sub) : (KEY_MISS | sub);
-      const uint32_t k1 = dpp_u<QP_ROT1>(key), k2 = dpp_u<QP_ROT2>(key), k3 = dpp_u<QP_ROT3>(key);
-      const int rank = (int)(k1 < key) + (int)(k2 < key) + (int)(k3 < key);
-      const uint32_t nearest = quad_or((hit && rank == 0) ? (uint32_t)ref : 0u);
-      if (hit && rank > 0) stk_ray[(sp + nh - 1 - rank) * 16] = ref;   // farthest child deepest
-      if (nh == 0) { sp--; cur = stk_ray[sp * 16]; }
-      else { cur = (int)nearest; sp += nh - 1; }
-    }
-
-    // ---- (C) the node is not interior: finished, leave-instance marker, TLAS leaf or BLAS leaf
-    if (COUNT && lane == (uint32_t)__builtin_ctzll(__ballot(true))) { diag_busy++; }
-    if (cur == REF_DONE) {
-      // handled below at a wave-uniform point
-    } else if (cur == REF_MARK) {
-      // leave the instance: world-space ray back from LDS
-      const float4 ro = s_world[wave][0][ray], rd = s_world[wave][1][ray];
-      co = mk3(ro.x, ro.y, ro.z); cd = mk3(rd.x, rd.y, rd.z);
-      rs = make_space(co, cd);
-      cur_inst = -1;
-      sp--; cur = stk[sp][ray];
-    } else if (cur_inst < 0) {
-      // TLAS leaf: enter the instance (all four lanes transform the same ray; t is preserved)
-      const int ii = ~cur;
-      const InstanceDev* I = a.sc.inst + ii;
-      if ((I->mask & 0xFFu) == 0u) { sp--; cur = stk[sp][ray]; }
-      else {
-        float m[12];
-        const float4* mp = reinterpret_cast<const float4*>(I->w2o);
-        float4 m0 = mp[0], m1 = mp[1], m2 = mp[2];
-        m[0] = m0.x; m[1] = m0.y; m[2] = m0.z; m[3] = m0.w; m[4] = m1.x; m[5] = m1.y; m[6] = m1.z; m[7] = m1.w;
-        m[8] = m2.x; m[9] = m2.y; m[10] = m2.z; m[11] = m2.w;
-        const F3 wo = co, wd = cd;
-        co = xform_point(m, wo); cd = xform_vec(m, wd);
-        rs = make_space(co, cd);
-        stk[sp][ray] = REF_MARK; sp++;
-        cur_inst = ii; cur = I->blas_root4;
-      }
-    } else {
-      // BLAS leaf: lane k tests triangle k
-      const uint32_t ref = (uint32_t)(~cur);
-      const uint32_t first = ref >> 3, count = (ref & 7u) + 1u;
-      float tt = __builtin_inff(), uu = 0.f, vv = 0.f;
-      int prim = 0x7FFFFFFF;
-      if (sub < count) {
-        const float4* tp = a.sc.tris + (size_t)(first + sub) * 3;
-        const float4 T0 = tp[0], T1 = tp[1], T2 = tp[2];
-        if (COUNT) cnt_tris++;
-        float t1, u1, v1;
-        if (tri_test(T0, T1, T2, co, cd, tmin, tmax, t1, u1, v1)) { tt = t1; uu = u1; vv = v1; prim = (int)__float_as_uint(T2.y); }
-      }
-      const float tq = quad_minf(tt);
-      if (tq < __builtin_inff()) {
-        const int pq = quad_mini(tt == tq ? prim : 0x7FFFFFFF);
-        const bool better = (best_inst < 0) || (tq < best_t) ||
-                            (tq == best_t && (cur_inst < best_inst || (cur_inst == best_inst && pq < best_prim)));
-        if (better) {
-          const bool win = (tt == tq) && (prim == pq);
-          best_u = __uint_as_float(quad_or(win ? __float_as_uint(uu) : 0u));
-          best_v = __uint_as_float(quad_or(win ? __float_as_uint(vv) : 0u));
-          best_t = tq; best_prim = pq; best_inst = cur_inst;
-        }
-      }
-      if (ANY && best_inst >= 0) cur = REF_DONE;   // any hit ends the ray (flags 13, src/shader.rgen:67)
-      else { sp--; cur = stk[sp][ray]; }
-    }
-    } while (false);
-
-    // ---- (D) finished rays: append the result to the wave's LDS out-list, ask for new work
-    const bool fin = !need && cur == REF_DONE;
-    const uint64_t fin_mask = __ballot(fin);
-    if (fin_mask != 0) {
-      if (fin && sub == 0) {
-        const uint32_t slot = out_count + (prefix_rank(fin_mask) >> 2);
-        if (MODE == MODE_SHADOW) {
-          // src/shader_shadow.rmiss:6 + src/shader.rgen:114-129: lit iff nothing was hit
-          float r, g, b;
-          if (best_inst < 0) { r = shc.x; g = shc.y; b = shc.z; }
-          else { const F3 amb = ambient_of(a.sc, __float_as_uint(shc.w)); r = amb.x; g = amb.y; b = amb.z; }
-          s_out[wave][slot] = make_float4(r, g, b, 1.0f);
-          s_outq[wave][slot] = make_int2((int)sid, 0);
-        } else {
-          s_out[wave][slot] = make_float4(best_t, best_u, best_v, __uint_as_float((uint32_t)best_prim));
-          s_outq[wave][slot] = make_int2((int)q, best_inst);
-        }
-      }
-      out_count += (uint32_t)__builtin_popcountll(fin_mask) >> 2;
-      if (fin) need = true;
-      if (out_count > 48u) flush();
-    }
-  }
-  if (COUNT) {
-    for (int off = 32; off > 0; off >>= 1) {
-      cnt_nodes += __shfl_down((unsigned long long)cnt_nodes, off);
-      cnt_tris += __shfl_down((unsigned long long)cnt_tris, off);
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      diag_iters += __shfl_down((unsigned long long)diag_iters, off);
-      diag_busy += __shfl_down((unsigned long long)diag_busy, off);
-    }
-    if (lane == 0) {
-      const int off = ANY ? (CNT_NODE_VISITS_SH - CNT_NODE_VISITS) : 0;
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_NODE_VISITS + off), (unsigned long long)cnt_nodes);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + CNT_TRI_TESTS + off), (unsigned long long)cnt_tris);
-      // diagnostic build only: interior-loop trips, other-phase trips and cycles of this wave
-      const int dg = ANY ? CNT_DIAG_SH : CNT_DIAG;
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg), (unsigned long long)diag_iters);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 2), (unsigned long long)diag_busy);
-      atomicAdd(reinterpret_cast<unsigned long long*>(a.counters + dg + 4), (unsigned long long)(__builtin_readcyclecounter() - diag_t0));
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------------------
 // k_shade: closest-hit / miss shading and path continuation for one bounce.  Persistent grid; a wave
@@ -2217,23 +1663,37 @@ static void launch_trace(const TraceArgs& a_in, bool counting, const LaunchCfg& 
   TraceArgs a = a_in;
   a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
   const dim3 g(cfg.trace_blocks), b(256);
-  if (cfg.variant == 0) {
-    if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, false>), g, b, 0, s, a);
-    else if (cfg.far || MODE == MODE_RAW) hipLaunchKernelGGL((k_trace<MODE, ANY, false, false, true>), g, b, 0, s, a);
-    else hipLaunchKernelGGL((k_trace<MODE, ANY, false, false, false>), g, b, 0, s, a);
-  } else if (cfg.variant == 2) {
+#ifdef RT_ALT_KERNELS
+  if (cfg.variant == 2) {
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace<MODE, ANY, true>), g, b, 0, s, a);
-  } else {
+    return;
+  }
+  if (cfg.variant == 1) {
     if (counting) hipLaunchKernelGGL((k_trace4<MODE, ANY, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace4<MODE, ANY, false>), g, b, 0, s, a);
+    return;
   }
+#endif
+  // (the product library has the one-lane BVH2 kernel only; rt_set_param refuses the other variants there: alt_kernels_built())
+  if (counting) hipLaunchKernelGGL((k_trace_count<MODE, ANY, false>), g, b, 0, s, a);
+  else if (cfg.far || MODE == MODE_RAW) hipLaunchKernelGGL((k_trace<MODE, ANY, false, false, true>), g, b, 0, s, a);
+  else hipLaunchKernelGGL((k_trace<MODE, ANY, false, false, false>), g, b, 0, s, a);
+}
+
+bool alt_kernels_built() {
+#ifdef RT_ALT_KERNELS
+  return true;
+#else
+  return false;
+#endif
 }
 
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, f.counters, bounce, f.shard_cap, f.ovf_stack);
   a.ray_o = f.ray_o[bounce & 1]; a.ray_d = f.ray_d[bounce & 1];
   a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
+#ifdef RT_ALT_KERNELS
   if (bounce == 0 && cfg.packet != 0 && cfg.variant == 0) {
     // one wavefront per chunk of primary rays (k_packet); with entry records the walk of each tile's rays starts at its record
     a.entry = f.entry;
@@ -2248,6 +1708,7 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
     }
     return;
   }
+#endif
   if (bounce == 0 && f.entry != nullptr && cfg.variant == 0) {
     // primary rays start at their tile's entry record (k_entry)
     a.entry = f.entry;
@@ -2272,6 +1733,7 @@ void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, c
   TraceArgs a = make_args(sc, f.counters, Q_SHADOW, f.shard_cap, f.ovf_stack);
   a.ray_o = f.sh_o; a.ray_d = f.sh_d; a.sh_c = f.sh_c;
   a.sample_color = f.sample_color;
+#ifdef RT_ALT_KERNELS
   if (cfg.packet != 0 && cfg.variant == 0) {
     // one wavefront per chunk of shadow rays (k_packet); optionally from the records of the cube around the light
     const bool le = f.light_entry != nullptr && f.sh_e != nullptr;
@@ -2287,6 +1749,7 @@ void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, c
     }
     return;
   }
+#endif
   if (f.light_entry != nullptr && f.sh_e != nullptr && cfg.variant == 0) {
     // shadow rays start at the record of their tile of the cube around the light (k_entry, k_shade)
     a.entry = f.light_entry; a.sh_e = f.sh_e;
@@ -2304,6 +1767,7 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
                       int32_t* ovf_stack, uint32_t* counters, bool any_hit, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, counters, 0, shard_cap, ovf_stack);
   a.ray_o = ray_o; a.ray_d = ray_d; a.raw_out = out;
+#ifdef RT_ALT_KERNELS
   if (cfg.packet >= 2 && cfg.variant == 0) {
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.packet_blocks), b(256);
@@ -2311,21 +1775,24 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
     else { if (counting) hipLaunchKernelGGL((k_packet<MODE_RAW, false, true, false>), g, b, 0, s, a); else hipLaunchKernelGGL((k_packet<MODE_RAW, false, false, false>), g, b, 0, s, a); }
     return;
   }
+#endif
   if (any_hit) launch_trace<MODE_RAW, true>(a, counting, cfg, s);
   else launch_trace<MODE_RAW, false>(a, counting, cfg, s);
 }
 
 int tail_blocks_per_cu() {
-  // the smallest over the four instantiations: any of them may be the one in flight (counting, 4-ary records)
+  // the smallest over the instantiations: any of them may be the one in flight (counting; 4-ary records in the alt build)
   int n = 1 << 30, v = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<false, false>, 256, 0) != hipSuccess) return 0;
   n = min(n, v);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<true, false>, 256, 0) != hipSuccess) return 0;
   n = min(n, v);
+#ifdef RT_ALT_KERNELS
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<false, true>, 256, 0) != hipSuccess) return 0;
   n = min(n, v);
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&v, k_tail<true, true>, 256, 0) != hipSuccess) return 0;
   n = min(n, v);
+#endif
   return n;
 }
 
@@ -2338,13 +1805,15 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
   t.first_bounce = (uint32_t)first_bounce;
   t.barrier = f.counters + CNT_BARRIER; t.fault = f.counters + CNT_FAULT;
   const dim3 g((unsigned)tail_blocks), b(256);
+#ifdef RT_ALT_KERNELS
   if (cfg.variant == 2) {
     if (counting) hipLaunchKernelGGL((k_tail<true, true>), g, b, 0, s, t);
     else hipLaunchKernelGGL((k_tail<false, true>), g, b, 0, s, t);
-  } else {
-    if (counting) hipLaunchKernelGGL((k_tail<true, false>), g, b, 0, s, t);
-    else hipLaunchKernelGGL((k_tail<false, false>), g, b, 0, s, t);
+    return;
   }
+#endif
+  if (counting) hipLaunchKernelGGL((k_tail<true, false>), g, b, 0, s, t);
+  else hipLaunchKernelGGL((k_tail<false, false>), g, b, 0, s, t);
 }
 
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s) {

@@ -53,7 +53,7 @@ struct Mesh {
   float q_lo[3] = {0, 0, 0}, q_scale[3] = {1, 1, 1};
   std::vector<TriPacket> tris;
   int levels = 0;                 // interior levels of the BVH2 (bounds the traversal stack)
-  int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays (before the hot-node reordering)
+  int32_t node_base = 0, node_base4 = 0;   // position of this mesh's nodes / packets in the linked arrays
   int32_t root = 0;                        // index of the mesh's root node in the linked quantized array
   uint32_t tri_base = 0;
   uint32_t cover_first = 0, cover_count = 0;   // the mesh's frontier boxes in Scene::d_cover_boxes (primary-ray coverage mask)
@@ -91,7 +91,6 @@ struct Scene {
   WideNodeQ* d_wide = nullptr;         // variant 2, same numbering as d_blas_nodes
   float4* d_tris = nullptr;
   size_t n_blas_nodes = 0, n_blas4 = 0, n_tris = 0;
-  uint32_t n_hot = 0;                  // leading nodes of d_blas_nodes the traversal kernels keep in LDS (<= HOT_NODES)
   float* d_cover_boxes = nullptr;      // object-space frontier boxes of all meshes, 6 floats each (k_cover)
   uint32_t max_cover_count = 0;
   uint32_t tlas_cap = 1024;            // TLAS nodes per slot (grows when a sole owner needs more)
@@ -398,42 +397,7 @@ int link_blas(rt_ctx* c) {
     m.levels = bvh2_levels(mq.data(), mq.size(), 0);
     if (m.levels < 0) return fail(c, RT_ERR_DEVICE, "BLAS builder produced a node graph that is not a tree");
   }
-  // Hot-node order: the kernels keep the first HOT_NODES entries of the node array in LDS, so the nodes every ray meets —
-  // the top levels of every BLAS — are moved to the front: a breadth-first walk over all meshes at once (roots first, then
-  // their children, ...) names the first HOT_NODES interior nodes; everything below keeps its builder order (level by level
-  // for the device SAH builder, Morton order for the LBVH).  Roots and links are rewritten; any valid numbering
-  // gives the same hits.
-  {
-    std::vector<int32_t> hot;              // old indices in breadth-first order
-    hot.reserve(HOT_NODES);
-    std::vector<int32_t> frontier, next;
-    for (auto& m : S->meshes) if (m.built && !m.qnodes.empty()) frontier.push_back(m.node_base);
-    while (!frontier.empty() && hot.size() < (size_t)HOT_NODES) {
-      next.clear();
-      for (int32_t n : frontier) {
-        if (hot.size() >= (size_t)HOT_NODES) break;
-        hot.push_back(n);
-        const BvhNodeQ& q = nodes[n];
-        if (q.child0 >= 0) next.push_back(q.child0);
-        if (q.child1 >= 0 && q.child1 != q.child0) next.push_back(q.child1);
-      }
-      frontier.swap(next);
-    }
-    std::vector<int32_t> new_of(nn, -1);
-    for (size_t k = 0; k < hot.size(); k++) new_of[hot[k]] = (int32_t)k;
-    int32_t at = (int32_t)hot.size();
-    for (size_t i = 0; i < nn; i++) if (new_of[i] < 0) new_of[i] = at++;
-    std::vector<BvhNodeQ> moved(nn);
-    for (size_t i = 0; i < nn; i++) {
-      BvhNodeQ q = nodes[i];
-      if (q.child0 >= 0) q.child0 = new_of[q.child0];
-      if (q.child1 >= 0) q.child1 = new_of[q.child1];
-      moved[new_of[i]] = q;
-    }
-    nodes.swap(moved);
-    for (auto& m : S->meshes) if (m.built && !m.qnodes.empty()) m.root = new_of[m.node_base]; else m.root = m.node_base;
-    S->n_hot = (uint32_t)hot.size();
-  }
+  for (auto& m : S->meshes) m.root = m.node_base;
   // Frontier boxes for the primary-ray coverage mask (k_cover): walk every mesh breadth-first from its root until about
   // COVER_TARGET_BOXES child boxes are open, and keep those boxes (dequantized: the stored planes already contain the float
   // boxes with two quanta of margin) in object space.  A leaf met on the way contributes its box as it is.
@@ -608,7 +572,6 @@ SceneDev scene_dev(const rt_ctx* c) {
   s.verts = S->d_verts; s.idx = S->d_idx; s.sky = S->d_sky; s.n_inst = (int)c->h_inst.size();
   s.sky_w = S->sky_w; s.sky_h = S->sky_h;
   s.materials = S->d_materials; s.prim_material = S->d_prim_material; s.n_materials = S->n_materials;
-  s.n_hot = S->n_hot;
   s.cover_boxes = S->d_cover_boxes;
   for (int k = 0; k < 3; k++) { s.tlas_q_lo[k] = c->tlas_q_lo[k]; s.tlas_q_scale[k] = c->tlas_q_scale[k]; }
   return s;
@@ -1107,7 +1070,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   // profiles/r03_experiments.txt) — a packet visits the union of its rays' walks, 63 nodes + 33 triangles per 64 primary rays,
   // and its wave-uniform control flow runs on the CU's single scalar unit
   c->cfg.packet = 0; c->cfg.packet_blocks = c->n_cu * 8;
-  if (const char* env = getenv("RT_PACKET")) c->cfg.packet = std::max(0, std::min(2, atoi(env)));
+  if (const char* env = getenv("RT_PACKET")) c->cfg.packet = alt_kernels_built() ? std::max(0, std::min(2, atoi(env))) : 0;
   if (const char* env = getenv("RT_PACKET_BLOCKS_PER_CU")) { const int v = atoi(env); if (v > 0 && v <= 16) c->cfg.packet_blocks = c->n_cu * v; }
   c->tail_resident_per_cu = tail_blocks_per_cu();
   live_slots_add(device_id, 1);
@@ -1115,7 +1078,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_BLAS_BUILDER")) c->blas_builder = atoi(env) ? 1 : 0;
   if (const char* env = getenv("RT_TAIL_MIN_BLOCKS")) c->tail_min_blocks = std::max(1, atoi(env));
   if (getenv("RT_TAIL_FULL_GRID")) c->tail_full_grid = true;
-  if (const char* env = getenv("RT_TRACE_VARIANT")) { const int v = atoi(env); c->cfg.variant = (v >= 0 && v <= 2) ? v : 0; }
+  if (const char* env = getenv("RT_TRACE_VARIANT")) { const int v = atoi(env); c->cfg.variant = (v >= 0 && v <= 2 && alt_kernels_built()) ? v : 0; }
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
@@ -1398,6 +1361,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   std::string k(name);
   if (k == "trace_variant") {
     if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant must be 0, 1 or 2");
+    if (value != 0 && !alt_kernels_built()) return fail(c, RT_ERR_INVALID_ARGUMENT, "trace_variant 1 / 2 are not in the product library (measured slower): build librt_mi355x_alt.so with `make alt` and load it (RT_LIB_VARIANT=alt)");
     { int q = quiesce_scene(c); if (q) return q; }
     Scene* S = c->scene;
     const int before = c->cfg.variant;
@@ -1447,7 +1411,11 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   }
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
-  if (k == "packet_trace") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2"); c->cfg.packet = value; return RT_OK; }
+  if (k == "packet_trace") {
+    if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2");
+    if (value != 0 && !alt_kernels_built()) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace is not in the product library (measured slower): build librt_mi355x_alt.so with `make alt` and load it (RT_LIB_VARIANT=alt)");
+    c->cfg.packet = value; return RT_OK;
+  }
   if (k == "packet_blocks_per_cu") { if (value < 1 || value > 16) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_blocks_per_cu must be 1..16"); c->cfg.packet_blocks = c->n_cu * value; return RT_OK; }
   if (k == "shadow_entry") { if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "shadow_entry must be 0, 1 or 2"); if (value != c->shadow_entry) { c->light_built = false; c->light_seen_valid = false; } c->shadow_entry = value; return RT_OK; }
   if (k == "entry_max_instances") { if (value < 1 || value >= (int)ENTRY_NO_INST) return fail(c, RT_ERR_INVALID_ARGUMENT, "entry_max_instances out of range"); c->entry_max_instances = value; return RT_OK; }

@@ -185,11 +185,6 @@ constexpr inline int cnt_tail(int queue, int shard) { return CNT_TAILS + (queue 
 constexpr inline int cnt_work(int queue, int shard) { return CNT_WORKS + (queue * N_SHARDS + shard) * CNT_STRIDE; }
 
 constexpr uint32_t SID_DEAD = 0xFFFFFFFFu;   // padding lane of the primary queue
-#ifndef RT_HOT_NODES
-#define RT_HOT_NODES 0
-#endif
-constexpr int HOT_NODES = RT_HOT_NODES;      // leading BvhNodeQ entries (the top levels of every BLAS, rt_api link_blas) the one-lane
-                                             // traversal kernels copy into LDS: 12 KB, four 256-thread workgroups per CU still fit
 #ifndef RT_LDS_INSTANCES
 #define RT_LDS_INSTANCES 32
 #endif

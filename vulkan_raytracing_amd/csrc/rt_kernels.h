@@ -25,7 +25,6 @@ struct SceneDev {
   const MaterialDev* materials;   // row n4: MTL material table (NULL / n_materials == 0: the reference's hard-coded constants)
   const uint32_t* prim_material;  // material of every triangle of the index buffer (global primitive number = first_index / 3 + gl_PrimitiveID)
   int n_materials;
-  uint32_t n_hot;              // nodes [0, n_hot) of blas_nodes are the hot set (<= HOT_NODES), staged through LDS by k_trace
   const float* cover_boxes;    // object-space frontier boxes of every mesh (lo[3], hi[3]), InstanceDev::cover_first/count index them
 };
 
@@ -133,6 +132,8 @@ void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray
 // de-interleave n_shards gathered compact shards (shard_stride_px pixels apart) into the width x height frame
 void launch_assemble(const void* gathered, void* out, int width, int height, int band_rows, int n_shards, size_t shard_stride_px, bool rgba8, hipStream_t s);
 int trace_threads_per_block();
+// true in librt_mi355x_alt.so (-DRT_ALT_KERNELS): trace_variant 1 / 2 and packet_trace exist; the product library has the one-lane BVH2 kernels only
+bool alt_kernels_built();
 // resident workgroups of k_tail per CU (occupancy query; <= 0 on failure)
 int tail_blocks_per_cu();
 // host-only sizing rules (rt_api.cpp)
