@@ -114,6 +114,13 @@ typedef struct rt_stats {
                                 barrier gave up (its workgroups were not co-resident); the context stays off k_tail afterwards */
   uint32_t frames_rerendered; /* 1 when the frame these statistics belong to had to be rendered a second time (k_tail fault): a copy of
                                 the frame taken BEFORE this call returned (a gather or memcpy enqueued behind rt_trace_shard) is stale */
+  /* ABI 6 — tile blobs (rt_set_param "tile_blobs"): the nodes and triangle packets a screen tile's rays can touch, staged through LDS */
+  uint64_t blob_tiles;          /* tiles of this frame whose primary rays were walked in LDS */
+  uint64_t blob_tiles_refused;  /* tiles whose blob did not fit (nodes, packets, depth, arena): their rays took the global walk */
+  uint64_t blob_nodes;          /* nodes / triangle packets in all blobs of the frame */
+  uint64_t blob_tris;
+  uint64_t tile_rays;           /* primary rays walked in LDS (part of closest_rays) */
+  uint64_t tile_rays_handed_on; /* ... of which went on to the global walk because they could still hit another instance */
 } rt_stats;
 
 /* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */

@@ -1339,6 +1339,143 @@ def test_entry_points_are_result_identical(ctx):
     both(256, 256)
 
 
+def test_tile_blobs_are_result_identical(ctx):
+    """VERDICT r3 item 1 / north_star "BVH nodes and triangle packets staged through LDS": for every 8x8-pixel tile whose entry record
+    names an instance k_blob writes the nodes and triangle packets the tile's beam can touch as one blob, and k_trace_tile walks the
+    tile's primary rays through it in LDS (rt_set_param "tile_blobs", default on); rays that may still hit another instance of their
+    record are handed on to the global walk with their incumbent hit.  A blob must contain everything a ray of its tile can hit:
+    frames and ray counts are identical with it on and off, the frame equals the oracle's, and the statistics show the path was taken.
+    Cameras: the start-up one, inside an instance's box, sheared, partly off screen and very close (blobs that do not fit), far away
+    (the whole scene in a few tiles: refused blobs), behind the camera; band shards; overlapping instances (rays handed on: the
+    mirror teapot behind and beside the orbiting mesh); 17 instances; a one-instance scene; odd sample counts."""
+    import torch
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 408, 232
+
+    def both(w=W, h=H):
+        out = {}
+        for on in (1, 0):
+            ctx.set_param("tile_blobs", on)
+            img, st = ctx.trace(w, h, counting=True)
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.closest_rays, st)
+        ctx.set_param("tile_blobs", 1)
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1] and out[1][2] == out[0][2]
+        assert out[0][3].tile_rays == 0 and out[0][3].blob_tiles == 0
+        return out
+
+    base_u = sp.uniforms.copy()
+    try:
+        out = both()
+        st = out[1][3]
+        assert st.blob_tiles > 100 and st.tile_rays > 0.5 * st.closest_rays, (st.blob_tiles, st.tile_rays, st.closest_rays)
+        assert st.blob_nodes > st.blob_tiles and st.blob_tris > st.blob_tiles
+        ref, rc = sp.orc.render(W, H)
+        check_image(out[1][0], ref)
+        assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        for band, n in ((8, 3), (16, 2)):
+            rows_max = tiling.max_shard_rows(H, band, n)
+            shards = []
+            for s in range(n):
+                buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+                ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                ctx.synchronize()
+                shards.append(buf.cpu().numpy())
+            assert np.array_equal(tiling.assemble(shards, H, W, band), out[1][0])
+        handed_on = 0
+        for pos, extra in (((0.3, 0.2, 5.2), {}), ((3.5, 0.5, 9.0), {}), ((0.0, 0.0, 2000.0), {}), ((6.0, 1.0, 14.0), {}), ((-4.0, 3.0, 12.0), {"center_object_type": 2, "max_bounce_count": 5}),
+                           ((0.0, 0.0, 20.0), {"forward": (0.0, 0.0, 1.0)}), ((0.0, 0.0, 20.0), {"samples_per_pixel": 3}), ((1.0, 0.4, 16.0), {"samples_per_pixel": 7})):
+            u = base_u.copy()
+            u[0]["position"][:3] = pos
+            for k, v in extra.items():
+                if k == "forward":
+                    u[0][k][:3] = v
+                else:
+                    u[0][k] = v
+            sp.set_uniforms(u)
+            o = both()
+            handed_on += o[1][3].tile_rays_handed_on
+        u = base_u.copy()
+        u[0]["right"][:3] = (1.3, 0.2, 0.1); u[0]["up"][:3] = (0.15, 0.8, -0.1); u[0]["forward"][:3] = (0.1, -0.05, -1.4)
+        sp.set_uniforms(u); o2 = both()
+        ref, rc = sp.orc.render(W, H)
+        check_image(o2[1][0], ref)
+        handed_on += o2[1][3].tile_rays_handed_on + st.tile_rays_handed_on
+        assert handed_on > 0          # the teapot stands behind and beside the orbiting mesh: some rays had to go on
+    finally:
+        ctx.set_param("tile_blobs", 1)
+        sp.set_uniforms(base_u)
+    wl = workloads.make("cfg5", RES)
+    wl.apply(ctx, sky=scenes.synthetic_skybox(64))
+    o5 = both(480, 270)
+    assert o5[1][3].blob_tiles > 0
+    wl1 = workloads.make("cfg1", RES)
+    wl1.apply(ctx)
+    o1 = both(256, 256)
+    assert o1[1][3].blob_tiles > 0 and o1[1][3].tile_rays_handed_on == 0
+
+
+def test_jitter_table_is_bit_identical_to_evaluating_the_hash(ctx):
+    """k_raygen reads (ux, uy) of every sample from a table computed once per (width, height, spp, shard layout)
+    by the same device function (kernels.hip sample_uv / k_jitter_table) instead of evaluating two binary64 sines per sample and
+    frame (rt_set_param "jitter_table", default on).  Frames and ray counts are identical with it on and off: whole frames, odd
+    sizes that do not fill their last tiles, sample counts that need several workgroups per tile, band shards (their rows map to
+    other frame rows), more frame sizes than the scene keeps tables for (the oldest is dropped), and frame slots sharing a table."""
+    import torch
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj"), 1, 0, 2, 4, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.2)
+    base_u = sp.uniforms.copy()
+
+    def both(w, h, spp):
+        u = base_u.copy(); u[0]["samples_per_pixel"] = spp
+        sp.set_uniforms(u)
+        out = {}
+        for on in (1, 0, 1):
+            ctx.set_param("jitter_table", on)
+            img, st = ctx.trace(w, h)
+            if on in out:
+                assert np.array_equal(out[on][0], img)       # the second frame finds the table
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow))
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1], (w, h, spp)
+        return out[1][0]
+
+    try:
+        full = both(200, 120, 4)
+        ref, _ = sp.orc.render(200, 120)
+        check_image(full, ref)
+        for w, h, spp in ((203, 117, 4), (64, 64, 1), (131, 77, 3), (96, 40, 7), (40, 24, 9), (8, 8, 2), (1, 1, 4), (333, 5, 2), (17, 190, 5), (72, 72, 4)):
+            both(w, h, spp)                                   # > 8 sizes: tables are dropped and rebuilt
+        both(200, 120, 4)
+        u = base_u.copy(); u[0]["samples_per_pixel"] = 4
+        sp.set_uniforms(u)
+        W, H = 200, 120
+        for on in (1, 0):
+            ctx.set_param("jitter_table", on)
+            for band, n in ((8, 3), (5, 2)):
+                rows_max = tiling.max_shard_rows(H, band, n)
+                shards = []
+                for s in range(n):
+                    buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+                    ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                    ctx.synchronize()
+                    shards.append(buf.cpu().numpy())
+                assert np.array_equal(tiling.assemble(shards, H, W, band), full), (on, band, n)
+        ctx.set_param("jitter_table", 1)
+        slots = [ctx.frame_slot() for _ in range(2)]
+        try:
+            for c in slots:
+                c.set_instances(sp.instances); c.set_uniforms(u)
+                c.trace_async(W, H)
+            for c in slots:
+                img, _ = c.trace_wait()
+                assert np.array_equal(img, full)
+        finally:
+            for c in slots:
+                c.close()
+    finally:
+        ctx.set_param("jitter_table", 1)
+        sp.set_uniforms(base_u)
+
+
 def test_entry_records_keep_the_far_flag_of_the_instance_they_enter(ctx):
     """a primary ray that starts from an entry record which names an instance is moved into that instance's
     object space at refill; whether it is FAR there (kernels.hip quant_far) must be decided against the MESH's quantisation, not

@@ -684,6 +684,39 @@ __global__ __launch_bounds__(64) void k_entry(SceneDev sc, EntryViews views) {
   }
 }
 
+// src/shader.rgen:62-75: where sample i of pixel (x, y) of a W x H frame crosses the image plane, (ux, uy) in [-1, 1].  A function of the
+// pixel, the sample index and the frame size only — neither camera nor scene enter — so it is computed ONCE per (W, H, spp, shard
+// layout) into a table (k_jitter_table; SURVEY.md §8(c)(2) proposes exactly this) and k_raygen reads 8 bytes per sample instead of
+// evaluating two binary64 sines and two IEEE divisions per sample and frame.  Same function, same bits.
+__device__ __forceinline__ float2 sample_uv(uint32_t x, uint32_t y, uint32_t i, uint32_t spp, int width, int height) {
+  const float fx = (float)x, fy = (float)y;
+  const float seed0 = (float)(spp + i), seed1 = seed0 + 0.5f;
+  float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)width;
+  float uy = (fy + jitter_hash(fx, fy, seed1)) / (float)height;
+  ux = __builtin_fmaf(ux, 2.0f, -1.0f);
+  uy = -__builtin_fmaf(uy, 2.0f, -1.0f);
+  return make_float2(ux, uy);
+}
+// local row of a shard's compact image -> row of the full frame (interleaved bands)
+__device__ __forceinline__ uint32_t frame_row(const FrameDev& f, uint32_t ly) {
+  if (f.n_shards == 1) return ly;
+  const uint32_t band = ly / (uint32_t)f.band_rows, within = ly - band * (uint32_t)f.band_rows;
+  return (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + within;
+}
+// table entry of (tile, sample, lane): tile-major, so that a wavefront of k_raygen reads 512 consecutive bytes
+__device__ __forceinline__ size_t jitter_index(uint32_t tile, uint32_t i, uint32_t spp, uint32_t lane) { return ((size_t)tile * spp + i) * 64u + lane; }
+
+// same grid as k_raygen
+__global__ __launch_bounds__(256) void k_jitter_table(FrameDev f, uint32_t spp, float2* table) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t i = blockIdx.z * blockDim.y + threadIdx.y;
+  const uint32_t x = blockIdx.x * 8u + (lane & 7u), ly = blockIdx.y * 8u + (lane >> 3);
+  if (i >= spp) return;
+  float2 uv = make_float2(0.f, 0.f);
+  if (x < (uint32_t)f.width && ly < (uint32_t)f.rows) uv = sample_uv(x, frame_row(f, ly), i, spp, f.width, f.height);
+  table[jitter_index(blockIdx.y * gridDim.x + blockIdx.x, i, spp, lane)] = uv;
+}
+
 __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u) {
   // grid (tiles_x, tiles_y, sample groups), block (64 lanes = one 8x8 tile, up to 4 samples): no index division
   const uint32_t spp = u.samples_per_pixel;
@@ -708,23 +741,17 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   // entry lists (k_entry): the record of this tile says whether its beam touches anything at all
   const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
   if (f.entry != nullptr && covered && (uint32_t)f.entry[tile].w[0] == ENTRY_EMPTY) covered = false;
+  // tile blobs (k_blob): the rays of a tile that has one are walked in LDS by k_trace_tile
+  uint32_t blob = BLOB_NONE;
+  if (f.tile_blob != nullptr && covered) blob = f.tile_blob[tile];
   bool survive = false;
   F3 d = mk3(0.f, 0.f, 1.f);
   uint32_t sid = 0;
   float4 miss_col = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
-    uint32_t y = ly;   // local row -> frame row of this shard's interleaved bands
-    if (f.n_shards != 1) {
-      const uint32_t band = f.band_rows == 8 ? blockIdx.y : ly / (uint32_t)f.band_rows;
-      const uint32_t within = f.band_rows == 8 ? (lane >> 3) : ly % (uint32_t)f.band_rows;
-      y = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * (uint32_t)f.band_rows + within;
-    }
-    const float fx = (float)x, fy = (float)y;
-    const float seed0 = (float)(spp + i), seed1 = seed0 + 0.5f;
-    float ux = (fx + jitter_hash(fx, fy, seed0)) / (float)f.width;
-    float uy = (fy + jitter_hash(fx, fy, seed1)) / (float)f.height;
-    ux = __builtin_fmaf(ux, 2.0f, -1.0f);
-    uy = -__builtin_fmaf(uy, 2.0f, -1.0f);
+    // (the table of this frame size and shard layout, when the host has one: rt_api jitter tables)
+    const float2 uv = f.jitter != nullptr ? f.jitter[jitter_index(tile, i, spp, lane)] : sample_uv(x, frame_row(f, ly), i, spp, f.width, f.height);
+    const float ux = uv.x, uy = uv.y;
     F3 right = mk3(u.right[0], u.right[1], u.right[2]), up = mk3(u.up[0], u.up[1], u.up[2]), fwd = mk3(u.forward[0], u.forward[1], u.forward[2]);
     d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
     sid = i * (uint32_t)(f.rows * f.width) + ly * (uint32_t)f.width + x;
@@ -763,6 +790,21 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   const bool fuse = gridDim.z == 1u;
   __shared__ float4 s_col[4][64];
   __shared__ unsigned long long s_miss[4];
+  if (fuse && !covered) {
+    // a tile no mesh can touch (uniform over the workgroup; 4/5 of the headline's tiles): every sample is a miss, so there is no queue
+    // run to allocate and no vote to take — exchange the colours, sum, store, done
+    s_col[threadIdx.y][lane] = miss_col;
+    __syncthreads();
+    if (threadIdx.y == 0 && live) {
+      float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
+      for (uint32_t w = 0; w < blockDim.y; w++) { const float4 c = s_col[w][lane]; r += c.x; g += c.y; b += c.z; al += c.w; }
+      const float nn = (float)spp;
+      const uint32_t p = ly * (uint32_t)f.width + x;
+      store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
+      st_stream(&f.sample_color[p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
+    }
+    return;
+  }
   if (fuse) {
     s_col[threadIdx.y][lane] = miss_col;
     const uint64_t mm = __ballot(missed);
@@ -779,6 +821,15 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     uint32_t tot = 0;
     for (uint32_t w = 0; w < blockDim.y; w++) { const uint32_t c = s_run[w]; s_run[w] = tot; tot += c; }
+    if (tot != 0u && blob != BLOB_NONE) {
+      // the run goes to the TOP of the shard's region (which grows downwards; queue 0 grows upwards from the bottom: a shard never
+      // receives more than shard_cap rays in all) and the tile joins the shard's work list
+      const uint32_t below = atomicAdd(f.counters + cnt_tail(Q_TILE_RAYS, (int)shard), tot);
+      const uint32_t start = f.shard_cap - (below + tot);
+      const uint32_t item = atomicAdd(f.counters + cnt_tail(Q_TILE_WORK, (int)shard), 1u);
+      f.tile_work[(size_t)shard * f.tile_work_cap + item] = make_uint4(tile, shard * f.shard_cap + start, tot, blob);
+      s_run[4] = start;
+    } else
     s_run[4] = tot ? atomicAdd(f.counters + cnt_tail(0, (int)shard), tot) : 0u;
   }
   __syncthreads();
@@ -880,13 +931,16 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 // FAR: the kernel carries the far-ray logic (quant_far).  The host launches the FAR = false instantiations whenever no ray of the
 // launch can be far — camera, scene extent and instance scales decide that per frame (rt_api far_possible) — so the headline pays
 // nothing for it; the record-level entry point (arbitrary origins) and k_tail always carry it.
-template <int MODE, bool ANY, bool COUNT, bool WIDE, bool ENTRY = false, bool FAR = true>
+// CONT (closest hit, ENTRY): the rays k_trace_tile handed on — walked in LDS through their tile's blob already, they carry their
+// incumbent hit (in the hit record of slot sh_e[entry]) and start from the REST words of their tile's record that their ray can
+// still reach (mask in o.w); the result goes back to the incumbent's slot.
+template <int MODE, bool ANY, bool COUNT, bool WIDE, bool ENTRY = false, bool FAR = true, bool CONT = false>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
-  __shared__ uint32_t s_ent[(ENTRY && MODE == MODE_SHADOW) ? 4 : 1][64];   // entry record of every ray of the current chunk
+  __shared__ uint32_t s_ent[((ENTRY && MODE == MODE_SHADOW) || CONT) ? 4 : 1][64];   // entry record of every ray of the current chunk (CONT: its hit-record slot)
   // Instance records staged through LDS: what "enter the instance" reads (world->object rows, dequantisation, root, mask)
   // for the first LDS_INSTANCES instances, 80 bytes each.  That phase runs for a quarter of the lanes at a time and was
   // spending ~1200 cycles per pass on the global-memory latency of these few, shared records.
@@ -936,12 +990,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     }
     if (lane < pf_count) {
       pf_o = ld_stream(&a.ray_o[pf_base + lane]); pf_d = ld_stream(&a.ray_d[pf_base + lane]);
-      if (ENTRY && MODE == MODE_SHADOW) pf_e = (uint32_t)ld_stream(reinterpret_cast<const int*>(a.sh_e) + pf_base + lane);
+      if ((ENTRY && MODE == MODE_SHADOW) || CONT) pf_e = (uint32_t)ld_stream(reinterpret_cast<const int*>(a.sh_e) + pf_base + lane);
     }
   };
   auto promote = [&]() {
     s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
-    if (ENTRY && MODE == MODE_SHADOW) s_ent[wave][lane] = pf_e;
+    if ((ENTRY && MODE == MODE_SHADOW) || CONT) s_ent[wave][lane] = pf_e;
     chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
     prefetch();
   };
@@ -1036,6 +1090,25 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           co = wo; cd = wd;
           cur_inst = -1;
           stk[0] = REF_DONE;
+          if (CONT) {
+            // handed on by k_trace_tile: the surviving REST words of the tile's record (far to near on the stack), the incumbent hit
+            const uint32_t ent = __float_as_uint(ro.w);
+            const uint32_t tile = ent & 0xFFFFFFu, mask = (ent >> 24) & 15u;
+            q = s_ent[wave][ci];                       // results go to the incumbent's slot
+            const int4* rp = reinterpret_cast<const int4*>(a.entry + tile);
+            const int4 r0 = rp[0], r1 = rp[1];
+            const uint32_t n_rest = (((uint32_t)r0.x >> 4) & 15u) - 1u;
+            const int wk[4] = {r0.z, r0.w, r1.x, r1.y};   // rest words, far to near (bottom first)
+            sp = 1;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++)
+              if (k < n_rest && ((mask >> (n_rest - 1u - k)) & 1u) != 0u) { stk[sp * 64] = wk[k]; sp++; }
+            sp--; cur = stk[sp * 64];
+            quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = false;
+            const float4 inc = a.hit_a[q];
+            best_t = inc.x; best_u = inc.y; best_v = inc.z; best_prim = (int)__float_as_uint(inc.w); best_inst = a.hit_inst[q];
+            need = false;
+          } else
           if (ENTRY) {
             // the walk starts at the record of the ray's tile (k_entry): its words go on the stack, its first node becomes the
             // current one, and the ray enters the record's instance here instead of in phase (C)
@@ -1079,7 +1152,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             sp = 1;
             cur = a.sc.tlas_root;   // TLAS root (always interior)
           }
-          best_t = (ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1;
+          if (!CONT) { best_t = (ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1; }
           need = false;
         }
         chunk_pos += n_need < avail ? n_need : avail;
@@ -1331,10 +1404,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
 // (five 256-thread workgroups per CU = five waves per SIMD is what the LDS admits: the register allocator of the shipped kernels
 // is held to that; the instrumented ones (k_trace_count) may take more registers rather than spill — a spill reload would
 // distort the very phase timings they exist to measure)
-template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU))) void k_trace(TraceArgs a) { trace_body<MODE, ANY, false, WIDE, ENTRY, FAR>(a); }
-template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true>
-__global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY, FAR>(a); }
+template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true, bool CONT = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_EU, RT_WAVES_PER_EU))) void k_trace(TraceArgs a) { trace_body<MODE, ANY, false, WIDE, ENTRY, FAR, CONT>(a); }
+template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true, bool CONT = false>
+__global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY, FAR, CONT>(a); }
+
+#include "kernels_tile.inc"   // k_blob, k_trace_tile: the tile's nodes and triangle packets staged through LDS
 
 #ifdef RT_ALT_KERNELS
 #include "kernels_alt.inc"   // k_packet, k_trace4: alternatives measured slower, only in librt_mi355x_alt.so
@@ -1356,9 +1431,13 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   const UniformsDev& U = a.u;
   const int cur = a.bounce & 1, nxt = cur ^ 1;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  // bounce 0 of a frame with tile blobs has its rays in two regions per shard: queue 0 at the bottom, the tile rays (walked by
+  // k_trace_tile) at the top — a second pass with the other count and offset
+  const int n_pass = (a.bounce == 0 && f.tile_blob != nullptr) ? 2 : 1;
+  for (int pass = 0; pass < n_pass; pass++) {
   uint32_t cnt[N_SHARDS], maxb = 0;
 #pragma unroll
-  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = ld_cursor(f.counters + cnt_tail(a.bounce, t)); maxb = max(maxb, (cnt[t] + 63u) >> 6); }
+  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = ld_cursor(f.counters + cnt_tail(pass ? Q_TILE_RAYS : a.bounce, t)); maxb = max(maxb, (cnt[t] + 63u) >> 6); }
   const uint32_t n_waves = gridDim.x * 4u;
   for (uint32_t g = blockIdx.x * 4u + wave; g < maxb * N_SHARDS; g += n_waves) {
     const uint32_t shard = g & (N_SHARDS - 1), base = (g >> 3) << 6;
@@ -1366,7 +1445,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
 #pragma unroll
     for (int t = 0; t < N_SHARDS; t++) n = (shard == (uint32_t)t) ? cnt[t] : n;
     if (base >= n) continue;
-    const uint32_t q = shard * f.shard_cap + base + lane;
+    const uint32_t q = shard * f.shard_cap + (pass ? f.shard_cap - n : 0u) + base + lane;
     bool push_next = false, push_shadow = false;
     F3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     float sh_tmax = 0.f; F3 sh_c = mk3(0, 0, 0); float sh_w = 0.f;
@@ -1497,6 +1576,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
       if (f.sh_e != nullptr) f.sh_e[v] = sh_ent;
     }
   }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body(a); }
@@ -1599,7 +1679,10 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
     auto cnt64 = [&](int word) { return (unsigned long long)ld_cursor(f.counters + word) | ((unsigned long long)ld_cursor(f.counters + word + 1) << 32); };
     if (t < (uint32_t)STAT_WORDS) {
       unsigned long long v = 0;
-      if (t == STAT_QUEUE0) v = s_q[0];
+      if (t == STAT_QUEUE0) v = s_q[0] + s_q[Q_TILE_RAYS];
+      else if (t == STAT_TILE_RAYS) v = s_q[Q_TILE_RAYS];
+      else if (t == STAT_CONT_RAYS) v = s_q[Q_CONT];
+      else if (t >= STAT_BLOB && t < STAT_BLOB + 4) v = ld_cursor(f.counters + CNT_BLOB_STATS + (int)(t - STAT_BLOB));
       else if (t == STAT_SECONDARY) { for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) v += s_q[b]; }
       else if (t == STAT_SHADOW) v = s_q[Q_SHADOW];
       else if (t == STAT_QUEUE1) v = s_q[1];
@@ -1638,6 +1721,13 @@ size_t raygen_block_count(int width, int rows, uint32_t spp) {
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s) {
   dim3 b; const dim3 g = raygen_grid(f.width, f.rows, u.samples_per_pixel, b);
   hipLaunchKernelGGL(k_raygen, g, b, 0, s, sc, f, u);
+}
+size_t jitter_table_elems(int width, int rows, uint32_t spp) {
+  return (size_t)(((uint32_t)width + 7u) >> 3) * (size_t)(((uint32_t)rows + 7u) >> 3) * spp * 64u;
+}
+void launch_jitter_table(const FrameDev& f, uint32_t spp, float2* table, hipStream_t s) {
+  dim3 b; const dim3 g = raygen_grid(f.width, f.rows, spp, b);
+  hipLaunchKernelGGL(k_jitter_table, g, b, 0, s, f, spp, table);
 }
 
 void launch_cover(const SceneDev& sc, const CoverViews& a, uint32_t max_boxes_per_instance, uint32_t* mask_block, hipStream_t s) {
@@ -1720,6 +1810,33 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
     return;
   }
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
+}
+
+void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, hipStream_t s) {
+  const uint32_t n = (uint32_t)(e.tiles_x * e.tile_rows);
+  if (n == 0 || f.tile_blob == nullptr) return;
+  BlobArgs a{sc, e, f.tile_blob, f.blob_arena, f.blob_slots, f.counters};
+  hipLaunchKernelGGL(k_blob, dim3(n), dim3(64), 0, s, a);
+}
+
+void launch_trace_tile(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+  if (f.tile_blob == nullptr) return;
+  TileArgs t{};
+  t.sc = sc; t.ray_o = f.ray_o[0]; t.ray_d = f.ray_d[0]; t.hit_a = f.hit_a; t.hit_inst = f.hit_inst;
+  t.cont_o = f.ray_o[1]; t.cont_d = f.ray_d[1]; t.cont_q = f.sh_e;
+  t.tile_work = f.tile_work; t.tile_work_cap = f.tile_work_cap; t.arena = f.blob_arena; t.counters = f.counters;
+  t.shard_cap = f.shard_cap; t.tmin = 0.001f;   // src/shader.rgen:87
+  const dim3 g(cfg.tile_blocks), b(256);
+  if (counting) hipLaunchKernelGGL((k_trace_tile<true>), g, b, 0, s, t);
+  else hipLaunchKernelGGL((k_trace_tile<false>), g, b, 0, s, t);
+  // the rays it handed on: from the rest words of their tile's record, with their incumbent hit
+  TraceArgs a = make_args(sc, f.counters, Q_CONT, f.shard_cap, f.ovf_stack);
+  a.ray_o = f.ray_o[1]; a.ray_d = f.ray_d[1]; a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
+  a.entry = f.entry; a.sh_e = f.sh_e;
+  a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = 8u;
+  const dim3 gc(cfg.trace_blocks);
+  if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true, false, true>), gc, b, 0, s, a);
+  else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false, true>), gc, b, 0, s, a);
 }
 
 void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s) {

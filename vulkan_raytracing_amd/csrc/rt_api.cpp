@@ -70,10 +70,22 @@ enum { CAT_RAYGEN = 0, CAT_TRACE, CAT_SHADE, CAT_SHADOW, CAT_RESOLVE, CAT_FRAME,
 // rt_create_frame_slot is that per-image part.  Each slot owns a TLAS region behind the BLAS nodes (one base pointer for
 // the kernels): slot k's TLAS nodes start at n_blas_nodes + k * tlas_cap.
 constexpr int MAX_SLOTS = 16;          // = MAX_TAILS_IN_FLIGHT: frame slots per scene
+// (ux, uy) of every sample of one frame size and shard layout (kernels.hip k_jitter_table): depends on neither camera nor scene, so
+// it is computed once and shared by every frame slot that renders that size (cfg3: 66 MB instead of two binary64 sines per sample and frame)
+struct JitterTable {
+  int W = 0, H = 0, rows = 0, band_rows = 0, shard = 0, n_shards = 0; uint32_t spp = 0;
+  float2* d = nullptr;
+  hipEvent_t ready = nullptr;          // the fill kernel is done (frames on other streams wait for it once)
+  uint64_t last_use = 0;
+};
+constexpr size_t MAX_JITTER_TABLES = 8;
+
 struct Scene {
   int device = 0;
   std::vector<rt_ctx*> members;        // every context that renders from this scene
   uint32_t slot_mask = 0;              // TLAS regions in use
+  std::vector<JitterTable> jitter_tables;
+  uint64_t jitter_clock = 0;
 
   // geometry (bindings 2/3)
   std::vector<float> h_verts;
@@ -128,6 +140,7 @@ struct rt_ctx {
   InstanceDev* d_inst[2] = {nullptr, nullptr};
   size_t cap_inst[2] = {0, 0};
   int parity = 0;
+  int tlas_node_count[2] = {0, 0};   // nodes of the TLAS uploaded for that parity
   hipEvent_t ev_frame[2] = {nullptr, nullptr};   // end of the last frame that read the buffers of that parity
   bool ev_frame_valid[2] = {false, false};
   float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
@@ -170,6 +183,8 @@ struct rt_ctx {
   int tail_blocks = TAIL_BLOCKS;   // grid of k_tail, clamped so that the tails of every live slot on the device are always co-resident
   int tail_resident_per_cu = 0;
   int tail_mode = 1;             // 0: one launch per bounce and kernel; 1: k_tail when the last frame had few secondary rays; 2: always k_tail
+  int jitter_table = 1;          // 1: k_raygen reads (ux, uy) from the scene's table of this frame size (bit-identical to evaluating the hash)
+  const float2* jitter_waited = nullptr; hipStream_t jitter_waited_stream = nullptr;   // the table / stream this context last ordered itself behind
   int primary_cover = 1;         // 1: k_cover marks the screen tiles the meshes can project onto, k_raygen skips the others (result-identical)
   int tail_min_blocks = 1;       // smallest k_tail grid (experiments: RT_TAIL_MIN_BLOCKS; RT_TAIL_FULL_GRID=1 always launches tail_blocks)
   bool tail_full_grid = false;
@@ -182,6 +197,15 @@ struct rt_ctx {
   int light_tiles = LIGHT_TILES_DEFAULT;   // tiles per side of a face of that cube
   EntryRec* d_entry = nullptr;   // one record per 8x8 tile of this slot's largest frame so far
   size_t entry_alloc_tiles = 0;
+  // tile blobs (rt_device.h; kernels_tile.inc): 1 = k_blob writes, for every tile whose record names an instance, the nodes and triangle packets the tile's beam
+  // can touch as one blob, and k_trace_tile walks the tile's primary rays through it in LDS (result-identical; needs entry_points)
+  int tile_blobs = 0;   // (first version: result-identical, slower — off until the fused version lands)
+  uint32_t* d_tile_blob = nullptr;   // directory, one word per tile (allocated with d_entry)
+  char* d_blob_arena = nullptr;
+  uint32_t blob_slots = 0;
+  uint4* d_tile_work = nullptr;
+  uint32_t tile_work_cap = 0;
+  size_t tile_dir_alloc = 0;
   EntryRec* d_light_entry = nullptr;   // 6 * light_tiles^2 records
   size_t light_alloc_tiles = 0;
   uint32_t* d_cover_mask = nullptr;   // TWO masks of cover_alloc_words: frame k uses one, its k_resolve clears the other
@@ -509,6 +533,7 @@ int upload_instances(rt_ctx* c, const std::vector<InstanceDev>& inst_dev) {
   const size_t n = inst_dev.size();
   std::vector<BvhNodeQ> tq;
   quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
+  c->tlas_node_count[c->parity] = (int)tq.size();
   const size_t need = std::max(tq.size(), c->tlas4.nodes.size());
   if (need > S->tlas_cap) {
     // a sole owner may grow the regions (nothing else reads the arrays); with several slots the arrays cannot move
@@ -568,6 +593,7 @@ SceneDev scene_dev(const rt_ctx* c) {
   SceneDev s{};
   s.nodes4 = S->d_nodes4; s.tlas_root4 = (int)tlas_base4(c);
   s.wide_nodes = S->d_wide; s.ovf_stride = c->ovf_stride;
+  s.tlas_nodes = c->tlas_node_count[c->parity];
   s.blas_nodes = S->d_blas_nodes; s.tlas_root = (int)tlas_base(c); s.tris = S->d_tris; s.inst = c->d_inst[c->parity];
   s.verts = S->d_verts; s.idx = S->d_idx; s.sky = S->d_sky; s.n_inst = (int)c->h_inst.size();
   s.sky_w = S->sky_w; s.sky_h = S->sky_h;
@@ -697,6 +723,43 @@ hipEvent_t take_event(rt_ctx* c) {
   return c->ev_pool[c->ev_used++];
 }
 
+// the scene's (ux, uy) table for this frame's size, sample count and shard layout; built on first use on stream s
+int jitter_table_for(rt_ctx* c, const FrameDev& f, uint32_t spp, hipStream_t s, const float2** out) {
+  Scene* S = c->scene;
+  *out = nullptr;
+  JitterTable* t = nullptr;
+  for (JitterTable& k : S->jitter_tables)
+    if (k.W == f.width && k.H == f.height && k.rows == f.rows && k.spp == spp && k.band_rows == f.band_rows && k.shard == f.shard && k.n_shards == f.n_shards) { t = &k; break; }
+  if (!t) {
+    if (S->jitter_tables.size() >= MAX_JITTER_TABLES) {
+      // drop the table used longest ago; frames of any slot may still read it, so the device drains first (rare: a scene that
+      // keeps changing its frame size)
+      HIP_TRY(c, hipDeviceSynchronize());
+      size_t lru = 0;
+      for (size_t k = 1; k < S->jitter_tables.size(); k++) if (S->jitter_tables[k].last_use < S->jitter_tables[lru].last_use) lru = k;
+      hipFree(S->jitter_tables[lru].d); hipEventDestroy(S->jitter_tables[lru].ready);
+      S->jitter_tables.erase(S->jitter_tables.begin() + (long)lru);
+      for (rt_ctx* m : S->members) m->jitter_waited = nullptr;
+    }
+    JitterTable n;
+    n.W = f.width; n.H = f.height; n.rows = f.rows; n.spp = spp; n.band_rows = f.band_rows; n.shard = f.shard; n.n_shards = f.n_shards;
+    HIP_TRY(c, hipMalloc((void**)&n.d, jitter_table_elems(f.width, f.rows, spp) * sizeof(float2)));
+    if (hipEventCreateWithFlags(&n.ready, hipEventDisableTiming) != hipSuccess) { hipFree(n.d); return fail(c, RT_ERR_DEVICE, "hipEventCreate failed"); }
+    launch_jitter_table(f, spp, n.d, s);
+    HIP_TRY(c, hipEventRecord(n.ready, s));
+    S->jitter_tables.push_back(n);
+    t = &S->jitter_tables.back();
+    c->jitter_waited = t->d; c->jitter_waited_stream = s;   // (stream order)
+  }
+  if (c->jitter_waited != t->d || c->jitter_waited_stream != s) {
+    HIP_TRY(c, hipStreamWaitEvent(s, t->ready, 0));
+    c->jitter_waited = t->d; c->jitter_waited_stream = s;
+  }
+  t->last_use = ++S->jitter_clock;
+  *out = t->d;
+  return RT_OK;
+}
+
 struct Span {
   rt_ctx* c; int cat; hipStream_t s; hipEvent_t a = nullptr;
   // An event record between two kernels costs ~10 us of idle GPU (measured: kernels of a frame run back to back without them),
@@ -765,6 +828,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // (a record opens ONE instance's BLAS; where the beam of a tile meets many instances — cfg5's ring of 16 — the TLAS phase of k_entry costs
   // more than the records save: measured 1.86 vs 1.80 ms per frame, profiles/r03_experiments.txt — so records are for scenes of few instances)
   const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && sc.n_inst <= c->entry_max_instances;
+  // far-ray logic in this frame's kernels only if some ray can be far (a re-render does not trust the context's current instance list: it carries the logic)
+  const bool far_frame = again != nullptr || far_possible(c, u);
+  // ... and the tiles' blobs on the records (no far-ray logic in the LDS walk: such frames keep the global walk)
+  const bool tile_on = entry_on && c->tile_blobs && !far_frame;
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
   // (kept records are paid once, so they also serve scenes of more instances than the per-frame camera records are worth building for)
   const bool light_on = cover_on && c->entry_points && c->cfg.variant == 0 && (entry_on || c->shadow_entry == 2) && c->shadow_entry &&
@@ -797,6 +864,26 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       c->entry_alloc_tiles = tiles_local;
     }
     f.entry = entry_on ? c->d_entry : nullptr;
+    if (tile_on) {
+      // directory (one word per tile), arena (a slot per tile that gets a blob; more tiles than slots: the rest take the global walk)
+      // and the shards' work lists (one item per k_raygen workgroup at most)
+      const uint32_t want_slots = (uint32_t)std::min<size_t>(tiles_local, tiles_local / 2 + 2048);
+      const uint32_t want_work = (uint32_t)(shard_cap / 256);
+      if (tiles_local > c->tile_dir_alloc || want_slots > c->blob_slots || want_work > c->tile_work_cap) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s));
+        if (c->d_tile_blob) HIP_TRY(c, hipFree(c->d_tile_blob));
+        if (c->d_blob_arena) HIP_TRY(c, hipFree(c->d_blob_arena));
+        if (c->d_tile_work) HIP_TRY(c, hipFree(c->d_tile_work));
+        c->d_tile_blob = nullptr; c->d_blob_arena = nullptr; c->d_tile_work = nullptr; c->tile_dir_alloc = 0; c->blob_slots = 0; c->tile_work_cap = 0;
+        const size_t dir = std::max(tiles_local, c->entry_alloc_tiles);
+        HIP_TRY(c, hipMalloc((void**)&c->d_tile_blob, dir * sizeof(uint32_t)));
+        HIP_TRY(c, hipMalloc((void**)&c->d_blob_arena, (size_t)want_slots * BLOB_SLOT_BYTES));
+        HIP_TRY(c, hipMalloc((void**)&c->d_tile_work, (size_t)N_SHARDS * want_work * sizeof(uint4)));
+        c->tile_dir_alloc = dir; c->blob_slots = want_slots; c->tile_work_cap = want_work;
+      }
+      f.tile_blob = c->d_tile_blob; f.blob_arena = c->d_blob_arena; f.blob_slots = c->blob_slots;
+      f.tile_work = c->d_tile_work; f.tile_work_cap = c->tile_work_cap;
+    }
     EntryArgs& ea = ev.v[0];   // (without camera records view 0 stays empty: no tiles, no blocks with work)
     if (entry_on) {
     for (int k = 0; k < 3; k++) ea.cam[k] = ca.cam[k];
@@ -856,8 +943,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // far-ray logic in this frame's kernels only if some ray can be far (a re-render decides again from the same inputs)
   LaunchCfg cfg = c->cfg;
   if (c->stack_need > 120) cfg.packet = 0;   // deeper than k_packet's 128-entry wave stack (a degenerate LBVH): the one-lane kernels spill to HBM instead
-  cfg.far = (again != nullptr || far_possible(c, u)) ? 1 : 0;   // (a re-render does not trust the context's current instance list: it carries the logic)
+  cfg.far = far_frame ? 1 : 0;
   f.far_possible = cfg.far;
+  if (c->jitter_table && rows > 0) { r = jitter_table_for(c, f, u.samples_per_pixel, s, &f.jitter); if (r) return r; }
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
   if (!c->timing || c->timed_frames >= 64) { c->ev_used = 0; c->spans.clear(); c->timed_frames = 0; }
@@ -885,6 +973,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       Span sp(c, CAT_RAYGEN, s);
       if (f.cover) launch_cover(sc, cv, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
       if (f.entry || ev.n > 1) launch_entry(sc, ev, s);
+      if (f.tile_blob) launch_blob(sc, ev.v[0], f, s);
       launch_raygen(sc, f, u, s);
     }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
@@ -917,7 +1006,9 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         break;
       }
       { LaunchCfg cc = cfg; if (b == 0 && cap_closest > 0) cc.trace_blocks = std::min(cfg.trace_blocks, c->n_cu * cap_closest);
-        Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cc, s); }
+        Span sp(c, CAT_TRACE, s);
+        if (b == 0 && f.tile_blob) launch_trace_tile(sc, f, c->counting, cc, s);   // the tiles with a blob: LDS walk (+ the rays it hands on)
+        launch_trace_closest(sc, f, (int)b, c->counting, cc, s); }
       { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
@@ -989,6 +1080,8 @@ int collect_stats(rt_ctx* c) {
     st.node_visits = hs[STAT_NODE_VISITS]; st.tri_tests = hs[STAT_TRI_TESTS];
     st.node_visits_shadow = hs[STAT_NODE_VISITS_SH]; st.tri_tests_shadow = hs[STAT_TRI_TESTS_SH];
     for (int k = 0; k < 6; k++) st.diag[k] = hs[STAT_DIAG + k];
+    st.blob_tiles = hs[STAT_BLOB]; st.blob_tiles_refused = hs[STAT_BLOB + 1]; st.blob_nodes = hs[STAT_BLOB + 2]; st.blob_tris = hs[STAT_BLOB + 3];
+    st.tile_rays = hs[STAT_TILE_RAYS]; st.tile_rays_handed_on = hs[STAT_CONT_RAYS];
   }
   st.bvh_node_bytes = c->cfg.variant == 1 ? sizeof(Bvh4Node) : c->cfg.variant == 2 ? sizeof(WideNodeQ) : sizeof(BvhNodeQ); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
@@ -1024,7 +1117,7 @@ int collect_stats(rt_ctx* c) {
 // ================================================================================================
 extern "C" {
 
-int rt_abi_version(void) { return 5; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials; 5: rt_stats::frames_rerendered, entry records, BGRA8
+int rt_abi_version(void) { return 6; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials; 5: rt_stats::frames_rerendered, entry records, BGRA8
 
 // Persistent traversal grid, workgroups per CU.  A lone context renders one frame at a time: the kernels are latency-bound and
 // 5 workgroups per CU (all the LDS admits) are fastest (cfg3: 1.00 ms vs 1.03 at 4, 1.28 at 2).  With several frame slots the
@@ -1064,6 +1157,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->cfg.trace_blocks = c->n_cu * 4;
   c->cfg.shade_blocks = c->n_cu * 8;
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
+  c->cfg.tile_blocks = c->n_cu * 5;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
   // k_packet (one wavefront per 64-ray chunk) is built and tested but OFF: measured slower (cfg3 lone frame 1.47 vs 0.95 ms;
@@ -1082,7 +1176,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1110,7 +1204,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e, c->d_fault_total,
+  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e, c->d_fault_total, c->d_tile_blob, c->d_blob_arena, c->d_tile_work,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
@@ -1127,6 +1221,7 @@ void rt_destroy(rt_ctx* c) {
   if (S->members.empty()) {   // the last context of a scene takes the shared arrays with it
     void* sp[] = {S->d_wide, S->d_nodes4, S->d_verts, S->d_idx, S->d_blas_nodes, S->d_tris, S->d_sky, S->d_materials, S->d_prim_material, S->d_cover_boxes};
     for (void* p : sp) if (p) hipFree(p);
+    for (JitterTable& t : S->jitter_tables) { hipFree(t.d); hipEventDestroy(t.ready); }
     delete S;
   }
   delete c;
@@ -1410,6 +1505,9 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
     c->out_rgba8 = value != 0; c->out_bgra = value != 0; return RT_OK;
   }
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
+  if (k == "jitter_table") { c->jitter_table = value != 0; return RT_OK; }
+  if (k == "tile_blobs") { c->tile_blobs = value != 0; return RT_OK; }
+  if (k == "tile_blocks_per_cu") { if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "tile_blocks_per_cu must be 1..8"); c->cfg.tile_blocks = c->n_cu * value; return RT_OK; }
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
   if (k == "packet_trace") {
     if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2");

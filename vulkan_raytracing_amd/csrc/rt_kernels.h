@@ -10,6 +10,7 @@ namespace rt {
 struct SceneDev {
   const BvhNodeQ* blas_nodes;  // variant 0: quantized BVH2 nodes of all meshes, then the quantized TLAS nodes
   int tlas_root;               // index of the TLAS root in blas_nodes
+  int tlas_nodes;              // nodes of this slot's TLAS (they follow the root)
   const float4* tris;          // 3 float4 per TriPacket
   float tlas_q_lo[3], tlas_q_scale[3];
   const WideNodeQ* wide_nodes; // variant 2: 4-ary records, same numbering as blas_nodes
@@ -66,6 +67,16 @@ struct FrameDev {
   uint32_t* sh_e;              // shadow queue: record index | ENTRY_REVERSE, or ENTRY_FROM_ROOT
   int light_tiles;
   int far_possible;            // LaunchCfg::far of this frame (k_raygen's TLAS test)
+  // (ux, uy) of every sample of this frame size and shard layout (k_jitter_table; NULL: k_raygen evaluates the hash itself)
+  const float2* jitter;
+  // Tile blobs (rt_device.h; NULL: off).  tile_blob[local tile] = arena slot of the tile's blob or BLOB_NONE (k_blob); k_raygen sends the
+  // rays of a tile with a blob to the top region of their shard and publishes (tile, first ray, count, slot) in tile_work;
+  // k_trace_tile walks them in LDS and hands the few that may still hit another instance on through the Q_CONT queue.
+  uint32_t* tile_blob;
+  char* blob_arena;
+  uint32_t blob_slots;         // arena capacity (slots of BLOB_SLOT_BYTES)
+  uint4* tile_work;            // N_SHARDS regions of tile_work_cap items
+  uint32_t tile_work_cap;
 };
 
 // camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
@@ -109,14 +120,22 @@ struct LaunchCfg {
   int packet;                  // variant 0 only.  1: the primary rays (bounce 0) and the shadow rays are walked by k_packet, one wavefront per
                                // 64-ray chunk; 2: the record-level entry (rt_intersect) too (tests: incoherent rays through the packet kernel)
   int packet_blocks;           // persistent grid of k_packet (no LDS, few registers: eight workgroups per CU fit)
+  int tile_blocks;             // persistent grid of k_trace_tile
 };
 
 size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
 void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
+// the (ux, uy) table k_raygen reads through FrameDev::jitter: jitter_table_elems float2 for (f.width, f.rows, spp) and f's shard layout
+size_t jitter_table_elems(int width, int rows, uint32_t spp);
+void launch_jitter_table(const FrameDev& f, uint32_t spp, float2* table, hipStream_t s);
 // bounce 0 of a frame with entry lists (f.entry) starts every ray at its tile's record
 void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, bool counting, const LaunchCfg& cfg, hipStream_t s);
 // one lane per tile of the shard: the record of every tile the coverage mask marks
 void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s);
+// one wavefront per tile of the camera view `e` (the view the records were made for): the tile's blob
+void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, hipStream_t s);
+// the rays of the tiles with a blob (LDS walk), then the rays it handed on (global walk from their record's rest words)
+void launch_trace_tile(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
 void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
