@@ -58,7 +58,7 @@ $(PKG)/librt_multi.so: host/rt_multi.cpp include/rt_multi.h include/rt_api.h $(P
 all: $(PKG)/librt_multi.so
 
 # headless C++ host (counterpart of the reference's main()); links the product libraries only
-rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so $(PKG)/librt_multi.so include/rt_host.hpp include/rt_multi.h
+rt_headless: host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp $(PKG)/librt_mi355x.so $(PKG)/librt_multi.so include/rt_host.hpp include/rt_multi.h include/rt_api.h
 	g++ -O2 -std=c++17 -pthread -Wall -Iinclude -o $@ host/rt_headless.cpp host/fly_camera.cpp host/standin.cpp host/standin_limbs.cpp host/jpeg_decode.cpp -L$(PKG) -lrt_multi -lrt_mi355x -Wl,-rpath,'$$ORIGIN/$(PKG)' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
 
 # kernel experiments: make exp EXP_NAME=<suffix> EXP_FLAGS="-DRT_EXP_..."  -> librt_mi355x_<suffix>.so (load with RT_LIB_VARIANT)

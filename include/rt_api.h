@@ -116,11 +116,14 @@ typedef struct rt_stats {
                                 the frame taken BEFORE this call returned (a gather or memcpy enqueued behind rt_trace_shard) is stale */
   /* ABI 6 — tile blobs (rt_set_param "tile_blobs"): the nodes and triangle packets a screen tile's rays can touch, staged through LDS */
   uint64_t blob_tiles;          /* tiles of this frame whose primary rays were walked in LDS */
-  uint64_t blob_tiles_refused;  /* tiles whose blob did not fit (nodes, packets, depth, arena): their rays took the global walk */
+  uint64_t blob_tiles_large;    /* ... of which needed the large size class (counting builds fill the blob_* fields) */
+  uint64_t blob_tiles_refused;  /* tiles whose blob fit no size class (nodes, packets, depth, arena): their rays took the global walk */
   uint64_t blob_nodes;          /* nodes / triangle packets in all blobs of the frame */
   uint64_t blob_tris;
   uint64_t tile_rays;           /* primary rays walked in LDS (part of closest_rays) */
   uint64_t tile_rays_handed_on; /* ... of which went on to the global walk because they could still hit another instance */
+  uint64_t tile_diag[6];        /* counting builds: wave cycles of k_tile before the walk (blob copy, ray generation), in the walk, in all; then from the
+                                   start of the workgroup until: its list entry is there, the blob is in LDS, the ray is set up */
 } rt_stats;
 
 /* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */

@@ -8,7 +8,8 @@ for spec in "$@"; do
   python3 - "$label" <<'PY' | tee -a "$out"
 import json, sys
 d = json.loads(open("gpurun_out/ab4_tmp.json").read().strip().splitlines()[-1])
-k = d.get("frame_kernel_ms") or {}
+k = (d.get("roofline") or {}).get("frame_kernel_ms") or {}
+k = {a: b for a, b in k.items() if isinstance(b, float)}
 print("%-34s ms/step %.4f  anim %.4f  lone %.4f  value %.0f | kernels %s | visits c %.2f s %.2f" % (
     sys.argv[1], d["ms_per_step"], d.get("animated_ms_per_step") or 0, d.get("ms_per_frame_single") or 0, d["value"],
     " ".join("%s %.3f" % (a, b) for a, b in k.items()), d.get("mean_node_visits_per_closest_ray") or 0, d.get("mean_node_visits_per_shadow_ray") or 0))

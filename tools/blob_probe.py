@@ -20,9 +20,13 @@ for on in (1, 0, 1, 0):
     ctx.set_param("tile_blobs", on)
     img, st = ctx.trace(W, H, counting=True)
     frames[on] = img
-    print("tile_blobs=%d counting: closest rays %d  tile rays %d (handed on %d)  blobs %d refused %d  nodes/blob %.1f tris/blob %.1f  visits/ray %.2f tris/ray %.2f" % (
-        on, st.closest_rays, st.tile_rays, st.tile_rays_handed_on, st.blob_tiles, st.blob_tiles_refused,
+    print("tile_blobs=%d counting: closest rays %d  tile rays %d (handed on %d)  blobs %d (large %d) refused %d  nodes/blob %.1f tris/blob %.1f  visits/ray %.2f tris/ray %.2f" % (
+        on, st.closest_rays, st.tile_rays, st.tile_rays_handed_on, st.blob_tiles, st.blob_tiles_large, st.blob_tiles_refused,
         st.blob_nodes / max(1, st.blob_tiles), st.blob_tris / max(1, st.blob_tiles), st.node_visits / max(1, st.closest_rays), st.tri_tests / max(1, st.closest_rays)))
+    if st.blob_tiles:
+        w = 4.0 * st.blob_tiles
+        print("   k_tile wave cycles (counting build): before the walk %.0f (entry there at %.0f, blob in LDS at %.0f, ray set up at %.0f)  walk %.0f  all %.0f per wave" % (
+            st.tile_diag[0] / w, st.tile_diag[3] / w, st.tile_diag[4] / w, st.tile_diag[5] / w, st.tile_diag[1] / w, st.tile_diag[2] / w))
     ctx.set_timing(1)
     for _ in range(3):
         ctx.trace(W, H)

@@ -17,6 +17,7 @@
 // -ffp-contract=off so nothing fuses unless written as __builtin_fmaf.  Box tests are the one
 // exception — they only have to be conservative, so they use v_rcp_f32 and a slack factor.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "rt_kernels.h"
 
@@ -742,8 +743,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
   if (f.entry != nullptr && covered && (uint32_t)f.entry[tile].w[0] == ENTRY_EMPTY) covered = false;
   // tile blobs (k_blob): the rays of a tile that has one are walked in LDS by k_trace_tile
-  uint32_t blob = BLOB_NONE;
-  if (f.tile_blob != nullptr && covered) blob = f.tile_blob[tile];
+  if (f.tile_blob != nullptr && covered && f.tile_blob[tile] != BLOB_NONE) return;   // (uniform over the workgroup) k_tile generates and walks this tile's rays
   bool survive = false;
   F3 d = mk3(0.f, 0.f, 1.f);
   uint32_t sid = 0;
@@ -821,15 +821,6 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     uint32_t tot = 0;
     for (uint32_t w = 0; w < blockDim.y; w++) { const uint32_t c = s_run[w]; s_run[w] = tot; tot += c; }
-    if (tot != 0u && blob != BLOB_NONE) {
-      // the run goes to the TOP of the shard's region (which grows downwards; queue 0 grows upwards from the bottom: a shard never
-      // receives more than shard_cap rays in all) and the tile joins the shard's work list
-      const uint32_t below = atomicAdd(f.counters + cnt_tail(Q_TILE_RAYS, (int)shard), tot);
-      const uint32_t start = f.shard_cap - (below + tot);
-      const uint32_t item = atomicAdd(f.counters + cnt_tail(Q_TILE_WORK, (int)shard), 1u);
-      f.tile_work[(size_t)shard * f.tile_work_cap + item] = make_uint4(tile, shard * f.shard_cap + start, tot, blob);
-      s_run[4] = start;
-    } else
     s_run[4] = tot ? atomicAdd(f.counters + cnt_tail(0, (int)shard), tot) : 0u;
   }
   __syncthreads();
@@ -931,16 +922,16 @@ constexpr uint32_t REFILL_MIN = RT_REFILL_MIN;
 // FAR: the kernel carries the far-ray logic (quant_far).  The host launches the FAR = false instantiations whenever no ray of the
 // launch can be far — camera, scene extent and instance scales decide that per frame (rt_api far_possible) — so the headline pays
 // nothing for it; the record-level entry point (arbitrary origins) and k_tail always carry it.
-// CONT (closest hit, ENTRY): the rays k_trace_tile handed on — walked in LDS through their tile's blob already, they carry their
-// incumbent hit (in the hit record of slot sh_e[entry]) and start from the REST words of their tile's record that their ray can
-// still reach (mask in o.w); the result goes back to the incumbent's slot.
+// CONT (closest hit, ENTRY): the queue may hold rays k_tile handed on (CONT_FLAG in o.w) — walked in LDS through their tile's blob
+// already, they carry their incumbent hit (in their own hit record) and start from the REST words of their tile's record that
+// their ray can still reach (mask in o.w).
 template <int MODE, bool ANY, bool COUNT, bool WIDE, bool ENTRY = false, bool FAR = true, bool CONT = false>
 __device__ __forceinline__ void trace_body(const TraceArgs& a) {
   __shared__ int s_stack[4][STACK2_LDS + 1][64];   // + one scratch row: lanes that do not push write there (fast_step)
   __shared__ float4 s_rays[4][2][64];
   __shared__ float4 s_out[4][64];
   __shared__ int2 s_outq[4][64];
-  __shared__ uint32_t s_ent[((ENTRY && MODE == MODE_SHADOW) || CONT) ? 4 : 1][64];   // entry record of every ray of the current chunk (CONT: its hit-record slot)
+  __shared__ uint32_t s_ent[(ENTRY && MODE == MODE_SHADOW) ? 4 : 1][64];   // entry record of every ray of the current chunk
   // Instance records staged through LDS: what "enter the instance" reads (world->object rows, dequantisation, root, mask)
   // for the first LDS_INSTANCES instances, 80 bytes each.  That phase runs for a quarter of the lanes at a time and was
   // spending ~1200 cycles per pass on the global-memory latency of these few, shared records.
@@ -990,12 +981,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
     }
     if (lane < pf_count) {
       pf_o = ld_stream(&a.ray_o[pf_base + lane]); pf_d = ld_stream(&a.ray_d[pf_base + lane]);
-      if ((ENTRY && MODE == MODE_SHADOW) || CONT) pf_e = (uint32_t)ld_stream(reinterpret_cast<const int*>(a.sh_e) + pf_base + lane);
+      if (ENTRY && MODE == MODE_SHADOW) pf_e = (uint32_t)ld_stream(reinterpret_cast<const int*>(a.sh_e) + pf_base + lane);
     }
   };
   auto promote = [&]() {
     s_rays[wave][0][lane] = pf_o; s_rays[wave][1][lane] = pf_d;
-    if ((ENTRY && MODE == MODE_SHADOW) || CONT) s_ent[wave][lane] = pf_e;
+    if (ENTRY && MODE == MODE_SHADOW) s_ent[wave][lane] = pf_e;
     chunk_base = pf_base; chunk_count = pf_count; chunk_pos = 0;
     prefetch();
   };
@@ -1090,11 +1081,12 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           co = wo; cd = wd;
           cur_inst = -1;
           stk[0] = REF_DONE;
-          if (CONT) {
-            // handed on by k_trace_tile: the surviving REST words of the tile's record (far to near on the stack), the incumbent hit
+          bool handed_on = false;
+          if (CONT && (__float_as_uint(ro.w) & CONT_FLAG) != 0u) {
+            // handed on by k_tile: the surviving REST words of the tile's record (far to near on the stack), the incumbent hit
+            handed_on = true;
             const uint32_t ent = __float_as_uint(ro.w);
             const uint32_t tile = ent & 0xFFFFFFu, mask = (ent >> 24) & 15u;
-            q = s_ent[wave][ci];                       // results go to the incumbent's slot
             const int4* rp = reinterpret_cast<const int4*>(a.entry + tile);
             const int4 r0 = rp[0], r1 = rp[1];
             const uint32_t n_rest = (((uint32_t)r0.x >> 4) & 15u) - 1u;
@@ -1107,7 +1099,6 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = false;
             const float4 inc = a.hit_a[q];
             best_t = inc.x; best_u = inc.y; best_v = inc.z; best_prim = (int)__float_as_uint(inc.w); best_inst = a.hit_inst[q];
-            need = false;
           } else
           if (ENTRY) {
             // the walk starts at the record of the ray's tile (k_entry): its words go on the stack, its first node becomes the
@@ -1152,7 +1143,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             sp = 1;
             cur = a.sc.tlas_root;   // TLAS root (always interior)
           }
-          if (!CONT) { best_t = (ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1; }
+          if (!(CONT && handed_on)) { best_t = (ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1; }
           need = false;
         }
         chunk_pos += n_need < avail ? n_need : avail;
@@ -1437,7 +1428,15 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   for (int pass = 0; pass < n_pass; pass++) {
   uint32_t cnt[N_SHARDS], maxb = 0;
 #pragma unroll
-  for (int t = 0; t < N_SHARDS; t++) { cnt[t] = ld_cursor(f.counters + cnt_tail(pass ? Q_TILE_RAYS : a.bounce, t)); maxb = max(maxb, (cnt[t] + 63u) >> 6); }
+  for (int t = 0; t < N_SHARDS; t++) {
+    if (pass) {   // the tile region: a fixed number of slots per blob of the shard's lists (kernels_tile.inc)
+      uint32_t blobs = 0;
+#pragma unroll
+      for (int k = 0; k < BLOB_CLASSES; k++) blobs += ld_cursor(f.counters + cnt_tail(Q_BLOB_LIST + k, t));
+      cnt[t] = blobs * (256u * ((U.samples_per_pixel + 3u) / 4u));
+    } else cnt[t] = ld_cursor(f.counters + cnt_tail(a.bounce, t));
+    maxb = max(maxb, (cnt[t] + 63u) >> 6);
+  }
   const uint32_t n_waves = gridDim.x * 4u;
   for (uint32_t g = blockIdx.x * 4u + wave; g < maxb * N_SHARDS; g += n_waves) {
     const uint32_t shard = g & (N_SHARDS - 1), base = (g >> 3) << 6;
@@ -1451,11 +1450,12 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
     float sh_tmax = 0.f; F3 sh_c = mk3(0, 0, 0); float sh_w = 0.f;
     uint32_t sh_ent = ENTRY_FROM_ROOT;
     uint32_t sid = SID_DEAD;
-    if (base + lane < n) {
+    int inst = HIT_DEAD;
+    if (base + lane < n) inst = ld_stream(&f.hit_inst[q]);
+    if (inst != HIT_DEAD) {   // (a slot of the tile region without a ray: nothing to shade)
       const float4 rd = ld_stream(&f.ray_d[cur][q]);
       sid = __float_as_uint(rd.w);
       const F3 d = mk3(rd.x, rd.y, rd.z);
-      const int inst = ld_stream(&f.hit_inst[q]);
       if (inst < 0) {
         // src/shader.rmiss:11 + src/shader.rgen:90-94
         const F3 c = sample_sky(a.sc, mk3(d.x, d.y, -d.z));
@@ -1679,10 +1679,11 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
     auto cnt64 = [&](int word) { return (unsigned long long)ld_cursor(f.counters + word) | ((unsigned long long)ld_cursor(f.counters + word + 1) << 32); };
     if (t < (uint32_t)STAT_WORDS) {
       unsigned long long v = 0;
-      if (t == STAT_QUEUE0) v = s_q[0] + s_q[Q_TILE_RAYS];
+      if (t == STAT_QUEUE0) { v = s_q[0] + s_q[Q_TILE_RAYS]; for (int k = 0; k < N_SHARDS; k++) v -= ld_cursor(f.counters + cnt_work(Q_TILE_RAYS, k)); }   // (a ray handed on counts once)
       else if (t == STAT_TILE_RAYS) v = s_q[Q_TILE_RAYS];
-      else if (t == STAT_CONT_RAYS) v = s_q[Q_CONT];
-      else if (t >= STAT_BLOB && t < STAT_BLOB + 4) v = ld_cursor(f.counters + CNT_BLOB_STATS + (int)(t - STAT_BLOB));
+      else if (t == STAT_CONT_RAYS) { for (int k = 0; k < N_SHARDS; k++) v += ld_cursor(f.counters + cnt_work(Q_TILE_RAYS, k)); }
+      else if (t >= STAT_BLOB && t < STAT_BLOB + 5) v = ld_cursor(f.counters + CNT_BLOB_STATS + (int)(t - STAT_BLOB));
+      else if (t >= STAT_TILE_DIAG && t < STAT_TILE_DIAG + 6) v = cnt64(CNT_TILE_DIAG + 2 * (int)(t - STAT_TILE_DIAG));
       else if (t == STAT_SECONDARY) { for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) v += s_q[b]; }
       else if (t == STAT_SHADOW) v = s_q[Q_SHADOW];
       else if (t == STAT_QUEUE1) v = s_q[1];
@@ -1804,6 +1805,11 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
     a.entry = f.entry;
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.trace_blocks), b(256);
+    if (f.tile_blob != nullptr) {   // queue 0 may hold rays k_tile handed on (tile blobs are off in frames with far rays)
+      if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true, false, true>), g, b, 0, s, a);
+      else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false, true>), g, b, 0, s, a);
+      return;
+    }
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true>), g, b, 0, s, a);
     else if (cfg.far) hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, true>), g, b, 0, s, a);
     else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false>), g, b, 0, s, a);
@@ -1812,31 +1818,29 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
   launch_trace<MODE_CLOSEST, false>(a, counting, cfg, s);
 }
 
-void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, hipStream_t s) {
+void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, bool counting, hipStream_t s) {
   const uint32_t n = (uint32_t)(e.tiles_x * e.tile_rows);
   if (n == 0 || f.tile_blob == nullptr) return;
-  BlobArgs a{sc, e, f.tile_blob, f.blob_arena, f.blob_slots, f.counters};
-  hipLaunchKernelGGL(k_blob, dim3(n), dim3(64), 0, s, a);
+  BlobArgs a{sc, e, f.tile_blob, f.blob_arena, f.blob_slots / N_SHARDS, f.blob_list, f.counters};
+  if (counting) hipLaunchKernelGGL((k_blob<true>), dim3(n), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL((k_blob<false>), dim3(n), dim3(64), 0, s, a);
 }
 
-void launch_trace_tile(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+template <int CLS>
+static void launch_tile_class(const TileArgs& t, uint32_t blocks, bool counting, hipStream_t s) {
+  if (counting) hipLaunchKernelGGL((k_tile<CLS, true>), dim3(blocks), dim3(256), 0, s, t);
+  else hipLaunchKernelGGL((k_tile<CLS, false>), dim3(blocks), dim3(256), 0, s, t);
+}
+void launch_tile(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, bool counting, hipStream_t s) {
   if (f.tile_blob == nullptr) return;
   TileArgs t{};
-  t.sc = sc; t.ray_o = f.ray_o[0]; t.ray_d = f.ray_d[0]; t.hit_a = f.hit_a; t.hit_inst = f.hit_inst;
-  t.cont_o = f.ray_o[1]; t.cont_d = f.ray_d[1]; t.cont_q = f.sh_e;
-  t.tile_work = f.tile_work; t.tile_work_cap = f.tile_work_cap; t.arena = f.blob_arena; t.counters = f.counters;
-  t.shard_cap = f.shard_cap; t.tmin = 0.001f;   // src/shader.rgen:87
-  const dim3 g(cfg.tile_blocks), b(256);
-  if (counting) hipLaunchKernelGGL((k_trace_tile<true>), g, b, 0, s, t);
-  else hipLaunchKernelGGL((k_trace_tile<false>), g, b, 0, s, t);
-  // the rays it handed on: from the rest words of their tile's record, with their incumbent hit
-  TraceArgs a = make_args(sc, f.counters, Q_CONT, f.shard_cap, f.ovf_stack);
-  a.ray_o = f.ray_o[1]; a.ray_d = f.ray_d[1]; a.hit_a = f.hit_a; a.hit_inst = f.hit_inst;
-  a.entry = f.entry; a.sh_e = f.sh_e;
-  a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = 8u;
-  const dim3 gc(cfg.trace_blocks);
-  if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true, false, true>), gc, b, 0, s, a);
-  else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false, true>), gc, b, 0, s, a);
+  t.sc = sc; t.f = f; t.u = u; t.sub_slots = f.blob_slots / N_SHARDS; t.tmin = 0.001f;   // src/shader.rgen:87
+  const uint32_t blocks = f.blob_slots / N_SHARDS * N_SHARDS;
+  launch_tile_class<0>(t, blocks, counting, s);
+  launch_tile_class<1>(t, blocks, counting, s);
+  launch_tile_class<2>(t, blocks, counting, s);
+  static const bool twice = getenv("RT_EXP_TILE_TWICE") != nullptr;   // experiment: the same launches again (warm TLB / caches): how much of k_tile is cold misses?
+  if (twice) { launch_tile_class<0>(t, blocks, counting, s); launch_tile_class<1>(t, blocks, counting, s); launch_tile_class<2>(t, blocks, counting, s); }
 }
 
 void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s) {

@@ -199,12 +199,12 @@ struct rt_ctx {
   size_t entry_alloc_tiles = 0;
   // tile blobs (rt_device.h; kernels_tile.inc): 1 = k_blob writes, for every tile whose record names an instance, the nodes and triangle packets the tile's beam
   // can touch as one blob, and k_trace_tile walks the tile's primary rays through it in LDS (result-identical; needs entry_points)
-  int tile_blobs = 0;   // (first version: result-identical, slower — off until the fused version lands)
+  int tile_blobs = 0;   // OFF by default: result-identical and measured slower (profiles/r04_experiments.txt: a wave of k_tile spends two thirds of its life
+                        // fetching its blob and storing its results, the walk itself is 2.6 x faster than the global one)
   uint32_t* d_tile_blob = nullptr;   // directory, one word per tile (allocated with d_entry)
   char* d_blob_arena = nullptr;
   uint32_t blob_slots = 0;
-  uint4* d_tile_work = nullptr;
-  uint32_t tile_work_cap = 0;
+  uint4* d_blob_list = nullptr;
   size_t tile_dir_alloc = 0;
   EntryRec* d_light_entry = nullptr;   // 6 * light_tiles^2 records
   size_t light_alloc_tiles = 0;
@@ -790,7 +790,10 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // k_raygen block b appends to shard b % 8, so a shard never receives more than this many rays; paths
   // stay in their shard, so the bound holds for every later queue as well
   const size_t raygen_blocks = raygen_block_count(W, rows, u.samples_per_pixel);
-  const size_t shard_cap = std::max<size_t>(256, ((raygen_blocks + N_SHARDS - 1) / N_SHARDS) * 256);
+  // (with tile blobs a shard also holds the tile region — a fixed 256 slots per blob and group of four samples, whether a ray fills
+  // them or not — while the rays k_tile hands on, at most as many again, go to queue 0 of the same shard; and k_tile sends ALL sample
+  // groups of a tile to shard tile % 8 where k_raygen spreads them: twice the room covers both)
+  const size_t shard_cap = std::max<size_t>(256, ((raygen_blocks + N_SHARDS - 1) / N_SHARDS) * 256) * (c->tile_blobs ? 2 : 1);
   const size_t capacity = shard_cap * N_SHARDS;
   int r = ensure_frame(c, capacity); if (r) return r;
   FrameDev f = c->frame;
@@ -865,24 +868,22 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     }
     f.entry = entry_on ? c->d_entry : nullptr;
     if (tile_on) {
-      // directory (one word per tile), arena (a slot per tile that gets a blob; more tiles than slots: the rest take the global walk)
-      // and the shards' work lists (one item per k_raygen workgroup at most)
-      const uint32_t want_slots = (uint32_t)std::min<size_t>(tiles_local, tiles_local / 2 + 2048);
-      const uint32_t want_work = (uint32_t)(shard_cap / 256);
-      if (tiles_local > c->tile_dir_alloc || want_slots > c->blob_slots || want_work > c->tile_work_cap) {
+      // directory (one word per tile), arena (N_SHARDS sub-arenas; a slot per tile that gets a blob — more tiles than slots: the rest take
+      // the global walk) and the blob lists (one part per size class and sub-arena, a slot's worth of entries each)
+      const uint32_t want_slots = (uint32_t)(((std::min<size_t>(tiles_local, tiles_local / 2 + 2048) + N_SHARDS - 1) / N_SHARDS + 8) * N_SHARDS);
+      if (tiles_local > c->tile_dir_alloc || want_slots > c->blob_slots) {
         HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s));
         if (c->d_tile_blob) HIP_TRY(c, hipFree(c->d_tile_blob));
         if (c->d_blob_arena) HIP_TRY(c, hipFree(c->d_blob_arena));
-        if (c->d_tile_work) HIP_TRY(c, hipFree(c->d_tile_work));
-        c->d_tile_blob = nullptr; c->d_blob_arena = nullptr; c->d_tile_work = nullptr; c->tile_dir_alloc = 0; c->blob_slots = 0; c->tile_work_cap = 0;
+        if (c->d_blob_list) HIP_TRY(c, hipFree(c->d_blob_list));
+        c->d_tile_blob = nullptr; c->d_blob_arena = nullptr; c->d_blob_list = nullptr; c->tile_dir_alloc = 0; c->blob_slots = 0;
         const size_t dir = std::max(tiles_local, c->entry_alloc_tiles);
         HIP_TRY(c, hipMalloc((void**)&c->d_tile_blob, dir * sizeof(uint32_t)));
         HIP_TRY(c, hipMalloc((void**)&c->d_blob_arena, (size_t)want_slots * BLOB_SLOT_BYTES));
-        HIP_TRY(c, hipMalloc((void**)&c->d_tile_work, (size_t)N_SHARDS * want_work * sizeof(uint4)));
-        c->tile_dir_alloc = dir; c->blob_slots = want_slots; c->tile_work_cap = want_work;
+        HIP_TRY(c, hipMalloc((void**)&c->d_blob_list, (size_t)BLOB_CLASSES * want_slots * sizeof(uint4)));
+        c->tile_dir_alloc = dir; c->blob_slots = want_slots;
       }
-      f.tile_blob = c->d_tile_blob; f.blob_arena = c->d_blob_arena; f.blob_slots = c->blob_slots;
-      f.tile_work = c->d_tile_work; f.tile_work_cap = c->tile_work_cap;
+      f.tile_blob = c->d_tile_blob; f.blob_arena = c->d_blob_arena; f.blob_slots = c->blob_slots; f.blob_list = c->d_blob_list;
     }
     EntryArgs& ea = ev.v[0];   // (without camera records view 0 stays empty: no tiles, no blocks with work)
     if (entry_on) {
@@ -973,7 +974,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       Span sp(c, CAT_RAYGEN, s);
       if (f.cover) launch_cover(sc, cv, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
       if (f.entry || ev.n > 1) launch_entry(sc, ev, s);
-      if (f.tile_blob) launch_blob(sc, ev.v[0], f, s);
+      if (f.tile_blob) launch_blob(sc, ev.v[0], f, c->counting, s);
       launch_raygen(sc, f, u, s);
     }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
@@ -1007,7 +1008,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       }
       { LaunchCfg cc = cfg; if (b == 0 && cap_closest > 0) cc.trace_blocks = std::min(cfg.trace_blocks, c->n_cu * cap_closest);
         Span sp(c, CAT_TRACE, s);
-        if (b == 0 && f.tile_blob) launch_trace_tile(sc, f, c->counting, cc, s);   // the tiles with a blob: LDS walk (+ the rays it hands on)
+        if (b == 0 && f.tile_blob) launch_tile(sc, f, u, c->counting, s);   // the tiles with a blob: their rays generated and walked in LDS (it hands a few on to queue 0)
         launch_trace_closest(sc, f, (int)b, c->counting, cc, s); }
       { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
@@ -1080,8 +1081,9 @@ int collect_stats(rt_ctx* c) {
     st.node_visits = hs[STAT_NODE_VISITS]; st.tri_tests = hs[STAT_TRI_TESTS];
     st.node_visits_shadow = hs[STAT_NODE_VISITS_SH]; st.tri_tests_shadow = hs[STAT_TRI_TESTS_SH];
     for (int k = 0; k < 6; k++) st.diag[k] = hs[STAT_DIAG + k];
-    st.blob_tiles = hs[STAT_BLOB]; st.blob_tiles_refused = hs[STAT_BLOB + 1]; st.blob_nodes = hs[STAT_BLOB + 2]; st.blob_tris = hs[STAT_BLOB + 3];
+    st.blob_tiles = hs[STAT_BLOB] + hs[STAT_BLOB + 1]; st.blob_tiles_large = hs[STAT_BLOB + 1]; st.blob_tiles_refused = hs[STAT_BLOB + 2]; st.blob_nodes = hs[STAT_BLOB + 3]; st.blob_tris = hs[STAT_BLOB + 4];
     st.tile_rays = hs[STAT_TILE_RAYS]; st.tile_rays_handed_on = hs[STAT_CONT_RAYS];
+    for (int k = 0; k < 6; k++) st.tile_diag[k] = hs[STAT_TILE_DIAG + k];
   }
   st.bvh_node_bytes = c->cfg.variant == 1 ? sizeof(Bvh4Node) : c->cfg.variant == 2 ? sizeof(WideNodeQ) : sizeof(BvhNodeQ); st.bvh_tri_bytes = sizeof(TriPacket);
   for (auto& sp : c->spans) {
@@ -1157,7 +1159,6 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   c->cfg.trace_blocks = c->n_cu * 4;
   c->cfg.shade_blocks = c->n_cu * 8;
   c->cfg.rays_per_lane = 4; c->cfg.min_blocks = c->n_cu;
-  c->cfg.tile_blocks = c->n_cu * 5;
   // default traversal kernel: 0 = one lane per ray over quantized BVH2 nodes (fastest measured); 1 = quad/BVH4
   c->cfg.variant = 0;
   // k_packet (one wavefront per 64-ray chunk) is built and tested but OFF: measured slower (cfg3 lone frame 1.47 vs 0.95 ms;
@@ -1204,7 +1205,7 @@ void rt_destroy(rt_ctx* c) {
   hipSetDevice(c->device);
   hipDeviceSynchronize();
   FrameDev& f = c->frame;
-  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e, c->d_fault_total, c->d_tile_blob, c->d_blob_arena, c->d_tile_work,
+  void* ptrs[] = {c->d_inst[0], c->d_inst[1], c->d_out_own, c->d_counters, c->d_ovf, c->d_cover_mask, c->d_entry, c->d_light_entry, f.sh_e, c->d_fault_total, c->d_tile_blob, c->d_blob_arena, c->d_blob_list,
                   f.ray_o[0], f.ray_o[1], f.ray_d[0], f.ray_d[1], f.hit_a, f.hit_inst, f.sh_o, f.sh_d, f.sh_c, f.sample_color};
   for (void* p : ptrs) if (p) hipFree(p);
   if (c->h_hint) hipHostFree(c->h_hint);
@@ -1507,7 +1508,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
   if (k == "jitter_table") { c->jitter_table = value != 0; return RT_OK; }
   if (k == "tile_blobs") { c->tile_blobs = value != 0; return RT_OK; }
-  if (k == "tile_blocks_per_cu") { if (value < 1 || value > 8) return fail(c, RT_ERR_INVALID_ARGUMENT, "tile_blocks_per_cu must be 1..8"); c->cfg.tile_blocks = c->n_cu * value; return RT_OK; }
+
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
   if (k == "packet_trace") {
     if (value < 0 || value > 2) return fail(c, RT_ERR_INVALID_ARGUMENT, "packet_trace must be 0, 1 or 2");

@@ -144,32 +144,40 @@ struct alignas(16) EntryRec { int32_t w[2 + ENTRY_WORDS]; };
 static_assert(sizeof(EntryRec) == 32, "EntryRec must be 32 bytes");
 constexpr int ENTRY_VIEWS = 7;                       // camera + 6 light faces
 constexpr int LIGHT_TILES_DEFAULT = 256;             // tiles per side of a light face (rt_set_param "light_tiles")
-// Tile blobs (k_blob / k_trace_tile, round 4): "BVH nodes and triangle packets staged through LDS".  For every 8x8-pixel tile whose
-// entry record names an instance, k_blob continues the beam search of k_entry down to the leaves and writes what the tile's beam can touch
-// of that instance's BLAS as ONE compact blob: the nodes in breadth-first order with blob-local links, then their triangle packets.  The
-// workgroup that owns the tile in k_trace_tile copies the blob into LDS with coalesced loads and walks the tile's <= 256 primary rays
-// there: a node visit is two ds_read_b128 instead of two divergent 16-byte requests to the CU's vector-memory path.
-//   header (BLOB_HEADER_WORDS x uint32, 64 bytes):
-//     [0] nodes  [1] triangle packets  [2] roots (1..BLOB_MAX_ROOTS)  [3] instance  [4] rest words (0..BLOB_MAX_REST)
-//     [5..11] the roots as 16-bit blob links (below), NEAR first   [12..15] the record's rest words (other instances / unopened TLAS nodes), near first
-//   then 3 x uint32 per rest word: its box in the TLAS quantisation (what the ray is tested against before it is handed on), 48 bytes
+// Tile blobs (k_blob / k_tile, round 4): "BVH nodes and triangle packets staged through LDS".  For every 8x8-pixel tile whose entry
+// record names an instance, k_blob continues the beam search of k_entry down to the leaves and writes what the tile's beam can touch of
+// that instance's BLAS as ONE compact blob: the nodes in breadth-first order with blob-local links, then their triangle packets.  The
+// workgroup that owns the tile in k_tile copies the blob into LDS with coalesced loads, generates the tile's primary rays
+// (src/shader.rgen:57-79) and walks them there: a node visit is two ds_read_b128 instead of two divergent 16-byte requests to the CU's
+// vector-memory path.  Arena slot of a blob (BLOB_SLOT_BYTES):
+//   [0, 28)    the roots as 16-bit blob links, NEAR first (BLOB_MAX_ROOTS words)
+//   [64, 112)  3 x uint32 per rest word of the record (other instances / unopened TLAS nodes, near first): its box in the TLAS
+//              quantisation — what a ray is tested against before it is handed on to the global walk
 //   nodes at byte BLOB_NODES_AT: BvhNodeQ whose two link words hold 16-bit BLOB LINKS — < 0x8000: node index in the blob;
 //     0x8000 | (first local packet << 3) | (count - 1): a leaf; a child the beam cannot touch keeps an inverted box (never entered) and
 //     the link BLOB_LINK_DONE, which is also the bottom-of-stack sentinel of the walk
 //   packets at byte BLOB_TRIS_AT: TriPacket copies
-constexpr int BLOB_MAX_NODES = 256;
-constexpr int BLOB_MAX_TRIS = 128;
-constexpr int BLOB_HEADER_WORDS = 16;
+// Blobs come in three size classes, walked by three instantiations of k_tile with different amounts of LDS: half of the tiles are small
+// and keep six workgroups per CU, the silhouette tiles (the beam grazes the surface: hundreds of triangles in depth) need up to four
+// times the room (measured on cfg3: median 149 nodes / 96 packets, 99th percentile 558 / 367; the figure with limbs 195 / 142 and
+// 763 / 578).  k_blob appends (slot, sizes, tile, instance) to the list of the blob's class; a tile whose blob fits none (or finds no
+// arena slot) keeps BLOB_NONE in the directory and its rays take the global walk (k_raygen -> k_trace<closest, ENTRY>).
+constexpr int BLOB_CLASSES = 3;
+constexpr int BLOB_CAP_NODES[BLOB_CLASSES] = {256, 384, 768};      // LDS: 8 / 12 / 24 KB of nodes,
+constexpr int BLOB_CAP_TRIS[BLOB_CLASSES] = {170, 256, 512};       //      8 / 12 / 24 KB of packets (+ 11 KB of stacks); whole multiples of 256 16-byte pieces:
+                                                                   //      every thread of k_tile copies the same number of pieces, unconditionally
+constexpr int BLOB_MAX_NODES = BLOB_CAP_NODES[BLOB_CLASSES - 1], BLOB_MAX_TRIS = BLOB_CAP_TRIS[BLOB_CLASSES - 1];
 constexpr int BLOB_REST_AT = 64;                                   // bytes
 constexpr int BLOB_NODES_AT = 128;
 constexpr int BLOB_TRIS_AT = BLOB_NODES_AT + BLOB_MAX_NODES * 32;
-constexpr int BLOB_SLOT_BYTES = BLOB_TRIS_AT + BLOB_MAX_TRIS * 48; // 14 464 bytes per arena slot
+constexpr int BLOB_SLOT_BYTES = BLOB_TRIS_AT + BLOB_MAX_TRIS * 48; // 49 280 bytes per arena slot
 constexpr int BLOB_MAX_ROOTS = 7;                                  // ENTRY_WORDS + 1
 constexpr int BLOB_MAX_REST = 4;                                   // ENTRY_TLAS_CAP
 constexpr uint32_t BLOB_LINK_LEAF = 0x8000u, BLOB_LINK_DONE = 0xFFFFu;
-constexpr uint32_t BLOB_NONE = 0xFFFFFFFFu;                        // tile directory: the tile's rays take the global walk (k_trace<closest, ENTRY>)
-constexpr int TILE_STACK = 20;                                     // per-lane stack rows of k_trace_tile (16-bit entries); k_blob refuses deeper blobs
-// a ray that k_trace_tile hands on to the global walk (it may still hit one of its record's REST words) carries in o.w:
+constexpr uint32_t BLOB_NONE = 0xFFFFFFFFu;                        // tile directory: the tile's rays take the global walk
+constexpr int TILE_STACK = 22;                                     // per-lane stack rows of k_tile (16-bit entries); k_blob refuses deeper blobs
+// list entry of a blob (uint4): x = arena slot, y = nodes | packets << 16, z = local tile, w = instance | roots << 24 | rest words << 28
+// a ray that k_tile hands on to the global walk (it may still hit one of its record's REST words) carries in o.w:
 constexpr uint32_t CONT_FLAG = 0x80000000u;                        // | surviving rest words (4 bits) << 24 | tile
 constexpr int N_SHARDS = 8;
 constexpr int CNT_STRIDE = 32;                 // uint32 words between cursors: one 128-byte line each
@@ -177,10 +185,12 @@ constexpr int CNT_MAX_BOUNCES = 72;            // bounce queues 0..71 (maxBounce
 constexpr int Q_SHADOW = CNT_MAX_BOUNCES;      // queue id of the shadow-ray queue
 // pseudo-queues of the tile path (bounce 0 only).  The rays of tiles with a blob live in the SAME arrays as bounce queue 0, at the
 // top end of each shard's region, growing downwards (queue 0 grows upwards; a shard never holds more than shard_cap rays in all):
-constexpr int Q_TILE_RAYS = CNT_MAX_BOUNCES + 1;   // tail = rays in the top region of the shard
-constexpr int Q_TILE_WORK = CNT_MAX_BOUNCES + 2;   // tail = work items (tile, first ray, count, blob) of the shard; work = cursor of k_trace_tile
-constexpr int Q_CONT = CNT_MAX_BOUNCES + 3;        // rays handed on by k_trace_tile (they wait in the bounce-1 arrays, unused until k_shade)
-constexpr int N_QUEUES = CNT_MAX_BOUNCES + 4;
+constexpr int Q_TILE_RAYS = CNT_MAX_BOUNCES + 1;   // tail = rays k_tile walked (statistics; their slots at the top of the shard's region follow from the list sizes);
+                                                   // work = rays k_tile handed on (they are in queue 0)
+constexpr int HIT_DEAD = -2;                       // hit_inst of a slot of the tile region that holds no ray (k_shade skips it)
+constexpr int Q_BLOB = CNT_MAX_BOUNCES + 2;        // tail = slots handed out in sub-arena `shard` (k_blob); work unused
+constexpr int Q_BLOB_LIST = CNT_MAX_BOUNCES + 3;   // + class: tail = blobs of that class in list part `shard`
+constexpr int N_QUEUES = Q_BLOB_LIST + BLOB_CLASSES;
 constexpr int TAIL_BLOCKS = 64;                // largest grid of k_tail (rt_api clamps it to the device: tail_grid())
 constexpr int MAX_TAILS_IN_FLIGHT = 16;        // k_tail launches (frame slots) that must be co-resident on one GPU at any time
 constexpr uint32_t TAIL_MAX_RAYS = 16384;      // bounces whose queue was larger in the previous frame get their own full-grid launches (k_tail then has at most one ray per lane: a 64-workgroup grid walks 26 k rays in 0.37 ms, the full grid in 0.05)
@@ -193,9 +203,9 @@ enum : int {
   CNT_DIAG_SH = 16,
   CNT_BARRIER = 24,        // k_tail grid barrier (arrivals)
   CNT_FAULT = 25,          // set by k_tail when a barrier gave up (reported as RT_ERR_DEVICE)
-  CNT_BLOB_CURSOR = 26,    // arena slots handed out by k_blob in this frame
-  CNT_BLOB_STATS = 27,     // 4 words: tiles with a blob, tiles that did not fit one, nodes, packets (all blobs of the frame)
-  CNT_TAILS = 32
+  CNT_TILE_DIAG = 32,      // 6 x uint64 (counting builds): wave cycles of k_tile before the walk, in it, in all; until the list entry is there, the blob is in LDS, the ray is set up
+  CNT_BLOB_STATS = 26,     // 5 words (counting builds): tiles with a small blob, with a large one, tiles that fit none, nodes, packets (all blobs of the frame)
+  CNT_TAILS = 48
 };
 // Compact per-frame statistics (uint64 each) that the last kernel of a frame writes to host-mapped memory, so that
 // reading a frame's counters needs no copy (a second device-to-host copy behind the pixel copy serialised the frames
@@ -210,10 +220,11 @@ enum StatSlot : int {
   STAT_DIAG = 9,          // 6 values
   STAT_FAULT_TOTAL = 15,  // frames of this context whose k_tail gave up, EVER (FrameDev::fault_total): unlike STAT_FAULT it survives the
                           // statistics of later frames enqueued behind a faulted one
-  STAT_BLOB = 16,         // 4 values: CNT_BLOB_STATS
-  STAT_TILE_RAYS = 20,    // primary rays walked in LDS by k_trace_tile
-  STAT_CONT_RAYS = 21,    // ... of which handed on to the global walk
-  STAT_WORDS = 24
+  STAT_BLOB = 16,         // 5 values: CNT_BLOB_STATS
+  STAT_TILE_RAYS = 21,    // primary rays walked in LDS by k_tile
+  STAT_CONT_RAYS = 22,    // ... of which handed on to the global walk
+  STAT_TILE_DIAG = 23,    // 6 values: CNT_TILE_DIAG
+  STAT_WORDS = 32
 };
 constexpr int CNT_WORKS = CNT_TAILS + N_QUEUES * N_SHARDS * CNT_STRIDE;
 constexpr int CNT_WORDS = CNT_WORKS + N_QUEUES * N_SHARDS * CNT_STRIDE;

@@ -69,14 +69,14 @@ struct FrameDev {
   int far_possible;            // LaunchCfg::far of this frame (k_raygen's TLAS test)
   // (ux, uy) of every sample of this frame size and shard layout (k_jitter_table; NULL: k_raygen evaluates the hash itself)
   const float2* jitter;
-  // Tile blobs (rt_device.h; NULL: off).  tile_blob[local tile] = arena slot of the tile's blob or BLOB_NONE (k_blob); k_raygen sends the
-  // rays of a tile with a blob to the top region of their shard and publishes (tile, first ray, count, slot) in tile_work;
-  // k_trace_tile walks them in LDS and hands the few that may still hit another instance on through the Q_CONT queue.
+  // Tile blobs (rt_device.h; NULL: off).  tile_blob[local tile] = arena slot of the tile's blob or BLOB_NONE (k_blob): k_raygen leaves
+  // the tiles that have one to k_tile, which generates their rays itself, walks them in LDS, puts them (ray direction + hit record) at the
+  // TOP of their shard's region of bounce queue 0 (Q_TILE_RAYS; k_shade reads both ends) and appends the few that may still hit
+  // another instance to queue 0 proper for the global walk.
   uint32_t* tile_blob;
   char* blob_arena;
-  uint32_t blob_slots;         // arena capacity (slots of BLOB_SLOT_BYTES)
-  uint4* tile_work;            // N_SHARDS regions of tile_work_cap items
-  uint32_t tile_work_cap;
+  uint32_t blob_slots;         // arena capacity (slots of BLOB_SLOT_BYTES): N_SHARDS sub-arenas of blob_slots / N_SHARDS
+  uint4* blob_list;            // BLOB_CLASSES x N_SHARDS parts of blob_slots / N_SHARDS entries
 };
 
 // camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
@@ -120,7 +120,6 @@ struct LaunchCfg {
   int packet;                  // variant 0 only.  1: the primary rays (bounce 0) and the shadow rays are walked by k_packet, one wavefront per
                                // 64-ray chunk; 2: the record-level entry (rt_intersect) too (tests: incoherent rays through the packet kernel)
   int packet_blocks;           // persistent grid of k_packet (no LDS, few registers: eight workgroups per CU fit)
-  int tile_blocks;             // persistent grid of k_trace_tile
 };
 
 size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
@@ -133,9 +132,9 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
 // one lane per tile of the shard: the record of every tile the coverage mask marks
 void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s);
 // one wavefront per tile of the camera view `e` (the view the records were made for): the tile's blob
-void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, hipStream_t s);
-// the rays of the tiles with a blob (LDS walk), then the rays it handed on (global walk from their record's rest words)
-void launch_trace_tile(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
+void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, bool counting, hipStream_t s);
+// the tiles with a blob: their primary rays generated and walked in LDS, one launch per size class
+void launch_tile(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, bool counting, hipStream_t s);
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
 void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
