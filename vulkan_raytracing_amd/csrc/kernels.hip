@@ -1417,6 +1417,8 @@ struct ShadeArgs {
   int bounce;
 };
 
+// TILE: bounce 0 of a frame with tile blobs — the hit records lie in two regions per shard (kernels_tile.inc)
+template <bool TILE = false>
 __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   const FrameDev& f = a.f;
   const UniformsDev& U = a.u;
@@ -1424,12 +1426,12 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // bounce 0 of a frame with tile blobs has its rays in two regions per shard: queue 0 at the bottom, the tile rays (walked by
   // k_trace_tile) at the top — a second pass with the other count and offset
-  const int n_pass = (a.bounce == 0 && f.tile_blob != nullptr) ? 2 : 1;
+  const int n_pass = TILE ? 2 : 1;
   for (int pass = 0; pass < n_pass; pass++) {
   uint32_t cnt[N_SHARDS], maxb = 0;
 #pragma unroll
   for (int t = 0; t < N_SHARDS; t++) {
-    if (pass) {   // the tile region: a fixed number of slots per blob of the shard's lists (kernels_tile.inc)
+    if (TILE && pass) {   // the tile region: a fixed number of slots per blob of the shard's lists (kernels_tile.inc)
       uint32_t blobs = 0;
 #pragma unroll
       for (int k = 0; k < BLOB_CLASSES; k++) blobs += ld_cursor(f.counters + cnt_tail(Q_BLOB_LIST + k, t));
@@ -1444,7 +1446,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
 #pragma unroll
     for (int t = 0; t < N_SHARDS; t++) n = (shard == (uint32_t)t) ? cnt[t] : n;
     if (base >= n) continue;
-    const uint32_t q = shard * f.shard_cap + (pass ? f.shard_cap - n : 0u) + base + lane;
+    const uint32_t q = shard * f.shard_cap + ((TILE && pass) ? f.shard_cap - n : 0u) + base + lane;
     bool push_next = false, push_shadow = false;
     F3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     float sh_tmax = 0.f; F3 sh_c = mk3(0, 0, 0); float sh_w = 0.f;
@@ -1579,7 +1581,8 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   }
 }
 
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body(a); }
+template <bool TILE>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body<TILE>(a); }
 
 // ------------------------------------------------------------------------------------------------
 // k_tail: bounces first..maxBounceCount of one frame in ONE launch.  After the first bounce a frame usually
@@ -1636,7 +1639,7 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
     if (ld_cursor(t.fault) != 0u) return;
     ShadeArgs sh = t.sh;
     sh.bounce = (int)b;
-    shade_body(sh);
+    shade_body<false>(sh);
     grid_barrier(t.barrier, t.fault, phase);
     if (ld_cursor(t.fault) != 0u) return;
   }
@@ -1939,7 +1942,8 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
 
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s) {
   ShadeArgs a{sc, f, u, bounce};
-  hipLaunchKernelGGL(k_shade, dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+  if (bounce == 0 && f.tile_blob != nullptr) hipLaunchKernelGGL((k_shade<true>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_shade<false>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
