@@ -39,7 +39,7 @@ class RtStats(C.Structure):
 
 
 EXPORTS = ["rt_create", "rt_create_frame_slot", "rt_destroy", "rt_upload_geometry", "rt_build_blas", "rt_set_instances", "rt_set_materials", "rt_set_instance_types", "rt_set_uniforms", "rt_set_skybox",
-           "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_assemble_shards", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
+           "rt_trace", "rt_trace_async", "rt_trace_wait", "rt_trace_shard", "rt_set_batch", "rt_trace_shard_batch", "rt_assemble_shards", "rt_shard_rows", "rt_synchronize", "rt_get_stats", "rt_set_timing", "rt_intersect",
            "rt_trace_counting", "rt_set_param", "rt_debug_check_builders", "rt_debug_sizing", "rt_last_error", "rt_device_info", "rt_abi_version"]
 
 _LIBS = {}
@@ -67,6 +67,8 @@ def lib(variant=None):
         L.rt_trace_async.argtypes = [vp, C.c_int, C.c_int]
         L.rt_trace_wait.argtypes = [vp, C.POINTER(vp), C.POINTER(RtStats)]
         L.rt_trace_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        L.rt_trace_shard_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        L.rt_set_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
         L.rt_assemble_shards.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.rt_shard_rows.argtypes = [C.c_int] * 4
         L.rt_synchronize.argtypes = [vp]
@@ -206,6 +208,18 @@ class RtContext:
     def trace_shard(self, W, H, band_rows, shard, n_shards, d_out_ptr, capacity_bytes, stream_ptr=None):
         self._chk(self.L.rt_trace_shard(self.h, W, H, band_rows, shard, n_shards, C.c_void_p(d_out_ptr), capacity_bytes,
                                         C.c_void_p(stream_ptr) if stream_ptr else None), "rt_trace_shard")
+
+    def set_batch(self, instances, uniforms, update=False):
+        """rt_set_batch: instances (K, n) records and K uniform blocks — K consecutive frames for one pass of the pipeline"""
+        inst = np.ascontiguousarray(instances, INSTANCE_DTYPE)
+        u = np.ascontiguousarray(uniforms, UNIFORMS_DTYPE).reshape(-1)
+        K = len(u)
+        inst = inst.reshape(K, -1)
+        self._chk(self.L.rt_set_batch(self.h, K, _p(inst), inst.shape[1], _p(u), int(update)), "rt_set_batch")
+
+    def trace_shard_batch(self, W, H, band_rows, shard, n_shards, d_out_ptr, capacity_bytes, stream_ptr=None):
+        self._chk(self.L.rt_trace_shard_batch(self.h, W, H, band_rows, shard, n_shards, C.c_void_p(d_out_ptr), capacity_bytes,
+                                              C.c_void_p(stream_ptr) if stream_ptr else None), "rt_trace_shard_batch")
 
     def assemble_shards(self, d_gathered_ptr, n_shards, shard_stride_bytes, W, H, band_rows, d_frame_ptr, capacity_bytes, stream_ptr=None):
         self._chk(self.L.rt_assemble_shards(self.h, C.c_void_p(d_gathered_ptr), n_shards, shard_stride_bytes, W, H, band_rows, C.c_void_p(d_frame_ptr),

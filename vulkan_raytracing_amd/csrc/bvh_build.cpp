@@ -483,28 +483,43 @@ void refit_bvh4(const BuiltBvh& b2, Bvh4& b4) {
     }
 }
 
-void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]) {
-  // bounds over every child box actually stored (refits can move them)
-  double lo[3] = {3e38, 3e38, 3e38}, hi[3] = {-3e38, -3e38, -3e38};
-  auto valid = [](const float* bx) { return bx[0] < 1e37f; };
+static bool box_valid(const float* bx) { return bx[0] < 1e37f; }
+
+void bvh2_bounds(const BuiltBvh& bvh, double lo[3], double hi[3]) {
+  // bounds over every child box actually stored (refits can move them); accumulates into lo / hi
   for (const BvhNode& n : bvh.nodes) {
     const float c0[6] = {n.a[0], n.a[1], n.a[2], n.a[3], n.c[0], n.c[1]}, c1[6] = {n.b[0], n.b[1], n.b[2], n.b[3], n.c[2], n.c[3]};
     for (const float* c : {c0, c1}) {
-      if (!valid(c)) continue;
+      if (!box_valid(c)) continue;
       for (int k = 0; k < 3; k++) { lo[k] = std::min(lo[k], (double)c[2 * k]); hi[k] = std::max(hi[k], (double)c[2 * k + 1]); }
     }
   }
-  double scale[3], base[3];
+}
+
+void quant_params(const double lo_in[3], const double hi_in[3], float q_lo[3], float q_scale[3]) {
   for (int k = 0; k < 3; k++) {
-    if (lo[k] > hi[k]) { lo[k] = hi[k] = 0.0; }
-    double ext = hi[k] - lo[k];
-    scale[k] = ext > 0 ? ext * (1.0 + 1e-6) / 65530.0 : 1e-30;
-    base[k] = lo[k] - 2.0 * scale[k];           // quanta 0,1 stay below every stored plane
-    q_lo[k] = (float)base[k]; q_scale[k] = (float)scale[k];
-    // the kernel uses the float values: re-derive the doubles from them so that rounding of base/scale
-    // cannot make a box non-conservative
-    base[k] = q_lo[k]; scale[k] = q_scale[k];
+    double lo = lo_in[k], hi = hi_in[k];
+    if (lo > hi) { lo = hi = 0.0; }
+    const double ext = hi - lo;
+    const double scale = ext > 0 ? ext * (1.0 + 1e-6) / 65530.0 : 1e-30;
+    q_lo[k] = (float)(lo - 2.0 * scale);           // quanta 0,1 stay below every stored plane
+    q_scale[k] = (float)scale;
   }
+}
+
+void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]) {
+  double lo[3] = {3e38, 3e38, 3e38}, hi[3] = {-3e38, -3e38, -3e38};
+  bvh2_bounds(bvh, lo, hi);
+  quant_params(lo, hi, q_lo, q_scale);
+  quantize_bvh2_in(bvh, out, q_lo, q_scale);
+}
+
+void quantize_bvh2_in(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, const float q_lo[3], const float q_scale[3]) {
+  auto valid = box_valid;
+  // the kernel uses the float values: the doubles are re-derived from them so that rounding of base/scale
+  // cannot make a box non-conservative
+  double scale[3], base[3];
+  for (int k = 0; k < 3; k++) { base[k] = q_lo[k]; scale[k] = q_scale[k]; }
   auto qdn = [&](double x, int k) { double q = std::floor((x - base[k]) / scale[k]) - 1.0; return (uint32_t)std::min(65535.0, std::max(0.0, q)); };
   auto qup = [&](double x, int k) { double q = std::ceil((x - base[k]) / scale[k]) + 1.0; return (uint32_t)std::min(65535.0, std::max(0.0, q)); };
   out.resize(bvh.nodes.size());

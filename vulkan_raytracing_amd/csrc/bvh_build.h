@@ -55,6 +55,11 @@ void refit_bvh4(const BuiltBvh& b2, Bvh4& b4);
 // 32-byte quantized form of bvh.nodes (rt_device.h BvhNodeQ).  q_lo/q_scale receive the dequantisation
 // of the tree's bounds.  A missing child (synthetic root of a one-leaf tree) becomes an inverted box no ray can enter; its link repeats the sibling's.
 void quantize_bvh2(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, float q_lo[3], float q_scale[3]);
+// the same in steps, for several trees that share ONE quantisation (the TLAS of every frame of a batch): accumulate the bounds of
+// each tree, derive the dequantisation, quantize each tree in it
+void bvh2_bounds(const BuiltBvh& bvh, double lo[3], double hi[3]);
+void quant_params(const double lo[3], const double hi[3], float q_lo[3], float q_scale[3]);
+void quantize_bvh2_in(const BuiltBvh& bvh, std::vector<BvhNodeQ>& out, const float q_lo[3], const float q_scale[3]);
 
 // 4-ary records (rt_device.h WideNodeQ) of `count` linked quantized nodes: out[i] holds the grandchildren of
 // nodes[i].  Interior links are global indices; node g of this tree sits at nodes[g - base].

@@ -160,6 +160,14 @@ __device__ __forceinline__ uint32_t wave_alloc(bool want, uint32_t* counter) {
   return base + prefix_rank(mask);
 }
 
+// frame of a sample id in a frame batch (<= BATCH_MAX = 8 frames of S sample ids each): three comparisons instead of a division
+__device__ __forceinline__ uint32_t frame_of(uint32_t sid, uint32_t S) {
+  uint32_t fi = sid >= 4u * S ? 4u : 0u;
+  fi += sid >= (fi + 2u) * S ? 2u : 0u;
+  fi += sid >= (fi + 1u) * S ? 1u : 0u;
+  return fi;
+}
+
 // Queue cursors are read with agent scope: inside k_tail a queue is filled by other workgroups of the same launch.
 __device__ __forceinline__ uint32_t ld_cursor(const uint32_t* p) {
   return __hip_atomic_load(const_cast<uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -374,7 +382,7 @@ __global__ __launch_bounds__(256) void k_cover(SceneDev sc, CoverViews views, ui
   // blockIdx.z = view: 0 the camera, 1..6 the faces of the cube around the light (entry lists of the shadow rays)
   const CoverArgs& a = views.v[blockIdx.z];
   uint32_t* const mask = mask_block + a.mask_offset;
-  const InstanceDev* I = sc.inst + blockIdx.y;
+  const InstanceDev* I = sc.inst + a.inst_base + blockIdx.y;
   const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= I->cover_count || (I->mask & 0xFFu) == 0u) return;
   const float* bx = sc.cover_boxes + 6u * (size_t)(I->cover_first + b);
@@ -602,7 +610,7 @@ __global__ __launch_bounds__(64) void k_entry(SceneDev sc, EntryViews views) {
   const F3 dc = mk3(uxc * e.basis[0] + uyc * e.basis[3] + e.kf * e.basis[6], uxc * e.basis[1] + uyc * e.basis[4] + e.kf * e.basis[7], uxc * e.basis[2] + uyc * e.basis[5] + e.kf * e.basis[8]);
   quant_space(cam, dc, sc.tlas_q_lo, sc.tlas_q_scale, P.qs, P.qb, P.rot);
   // ---- the TLAS: instances (and, beyond ENTRY_TLAS_CAP, unopened TLAS nodes) the beam can touch
-  int w = (work && sub == 0u) ? sc.tlas_root : ENTRY_FREE;
+  int w = (work && sub == 0u) ? sc.tlas_root + e.tlas_root_offset : ENTRY_FREE;
   float key = 0.0f;
   entry_open<true>(sc, P, w, key, ENTRY_TLAS_CAP, s_xw, s_xk);
   // every lane of the tile reads the whole TLAS list and orders it (near first) the same way
@@ -718,29 +726,35 @@ __global__ __launch_bounds__(256) void k_jitter_table(FrameDev f, uint32_t spp, 
   table[jitter_index(blockIdx.y * gridDim.x + blockIdx.x, i, spp, lane)] = uv;
 }
 
-__global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u) {
-  // grid (tiles_x, tiles_y, sample groups), block (64 lanes = one 8x8 tile, up to 4 samples): no index division
+__global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, UniformsDev u, BatchTab bt) {
+  // grid (tiles_x, tiles_y [x frames of a batch], sample groups), block (64 lanes = one 8x8 tile, up to 4 samples): no index division
   const uint32_t spp = u.samples_per_pixel;
   const uint32_t lane = threadIdx.x;
   const uint32_t i = blockIdx.z * blockDim.y + threadIdx.y;
   const uint32_t x = blockIdx.x * 8u + (lane & 7u);
-  const uint32_t ly = blockIdx.y * 8u + (lane >> 3);
+  // frame batch: the frames' tile rows are stacked in grid.y; fi = this workgroup's frame, by = its tile row in that frame (uniform)
+  uint32_t fi = 0, by = blockIdx.y;
+  if (f.batch_k > 1) { const uint32_t tile_rows1 = ((uint32_t)f.rows + 7u) >> 3; fi = blockIdx.y / tile_rows1; by = blockIdx.y - fi * tile_rows1; }
+  const uint32_t npx1 = (uint32_t)(f.rows * f.width);
+  const uint32_t ly = by * 8u + (lane >> 3);
   const bool live = i < spp && x < (uint32_t)f.width && ly < (uint32_t)f.rows;
   // coverage mask (uniform per workgroup): can any mesh touch this tile?  The local tile row maps to a tile row of the full
   // frame because bands are whole tiles when the mask is on (rt_api enables it only for band heights that are multiples of 8).
   bool covered = true;
-  if (f.cover != nullptr && f.cover[0] == 0u) {
-    uint32_t fty = blockIdx.y;
+  const uint32_t* const cover = f.cover != nullptr ? f.cover + (size_t)fi * f.cover_view_words : nullptr;
+  if (cover != nullptr && cover[0] == 0u) {
+    uint32_t fty = by;
     if (f.n_shards != 1) {
       const uint32_t tiles_per_band = (uint32_t)f.band_rows >> 3;
-      const uint32_t band = blockIdx.y / tiles_per_band, sub = blockIdx.y - band * tiles_per_band;
+      const uint32_t band = by / tiles_per_band, sub = by - band * tiles_per_band;
       fty = (band * (uint32_t)f.n_shards + (uint32_t)f.shard) * tiles_per_band + sub;
     }
     const uint32_t t = fty * (uint32_t)f.cover_tiles_x + blockIdx.x;
-    covered = ((f.cover[1u + (t >> 5)] >> (t & 31u)) & 1u) != 0u;
+    covered = ((cover[1u + (t >> 5)] >> (t & 31u)) & 1u) != 0u;
   }
   // entry lists (k_entry): the record of this tile says whether its beam touches anything at all
-  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;
+  const uint32_t tile = blockIdx.y * gridDim.x + blockIdx.x;   // (over all frames of a batch: the records of frame k follow those of frame k - 1)
+  const uint32_t tile1 = by * gridDim.x + blockIdx.x;          // within its frame
   if (f.entry != nullptr && covered && (uint32_t)f.entry[tile].w[0] == ENTRY_EMPTY) covered = false;
   // tile blobs (k_blob): the rays of a tile that has one are walked in LDS by k_trace_tile
   if (f.tile_blob != nullptr && covered && f.tile_blob[tile] != BLOB_NONE) return;   // (uniform over the workgroup) k_tile generates and walks this tile's rays
@@ -750,18 +764,19 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   float4 miss_col = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live) {
     // (the table of this frame size and shard layout, when the host has one: rt_api jitter tables)
-    const float2 uv = f.jitter != nullptr ? f.jitter[jitter_index(tile, i, spp, lane)] : sample_uv(x, frame_row(f, ly), i, spp, f.width, f.height);
+    const float2 uv = f.jitter != nullptr ? f.jitter[jitter_index(tile1, i, spp, lane)] : sample_uv(x, frame_row(f, ly), i, spp, f.width, f.height);
     const float ux = uv.x, uy = uv.y;
     F3 right = mk3(u.right[0], u.right[1], u.right[2]), up = mk3(u.up[0], u.up[1], u.up[2]), fwd = mk3(u.forward[0], u.forward[1], u.forward[2]);
+    if (f.batch_k > 1) { right = mk3(bt.right[fi][0], bt.right[fi][1], bt.right[fi][2]); up = mk3(bt.up[fi][0], bt.up[fi][1], bt.up[fi][2]); fwd = mk3(bt.forward[fi][0], bt.forward[fi][1], bt.forward[fi][2]); }
     d = normalize3(fma3(2.5f, fwd, fma3(uy, up, mul3(right, ux))));
-    sid = i * (uint32_t)(f.rows * f.width) + ly * (uint32_t)f.width + x;
+    sid = (fi * spp + i) * npx1 + ly * (uint32_t)f.width + x;
     if (covered) {
-      const F3 o = mk3(u.position[0], u.position[1], u.position[2]);
+      const F3 o = f.batch_k > 1 ? mk3(bt.position[fi][0], bt.position[fi][1], bt.position[fi][2]) : mk3(u.position[0], u.position[1], u.position[2]);
       F3 qs, qb; uint3 rot;
       quant_space(o, d, sc.tlas_q_lo, sc.tlas_q_scale, qs, qb, rot);
       const bool far = f.far_possible != 0 && quant_far(qs, qb);   // a camera hundreds of TLAS extents from the scene: the TLAS does not cull (see quant_far)
       // two levels of the TLAS: the boxes of the root and, where a child of the root is interior, of its children
-      const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root);
+      const uint4* rp = reinterpret_cast<const uint4*>(sc.blas_nodes + sc.tlas_root + (int)fi * sc.tlas_stride);
       const uint4 Q0 = rp[0], Q1 = rp[1];
       float tn;
       const bool h0 = far || slab_q(Q0.x, Q0.y, Q0.z, qs, qb, rot, 0.001f, 10000.0f, tn);
@@ -800,8 +815,8 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       for (uint32_t w = 0; w < blockDim.y; w++) { const float4 c = s_col[w][lane]; r += c.x; g += c.y; b += c.z; al += c.w; }
       const float nn = (float)spp;
       const uint32_t p = ly * (uint32_t)f.width + x;
-      store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
-      st_stream(&f.sample_color[p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
+      store_pixel(f, fi * npx1 + p, make_float4(r / nn, g / nn, b / nn, al / nn));
+      st_stream(&f.sample_color[fi * spp * npx1 + p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
     }
     return;
   }
@@ -833,16 +848,17 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
         float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
         for (uint32_t w = 0; w < blockDim.y; w++) { const float4 c = s_col[w][lane]; r += c.x; g += c.y; b += c.z; al += c.w; }
         const float nn = (float)spp;
-        const uint32_t p = ly * (uint32_t)f.width + x;     // = the sample id of sample 0
-        store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
-        st_stream(&f.sample_color[p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
+        const uint32_t p = ly * (uint32_t)f.width + x;     // = the sample id of sample 0 (in its frame)
+        store_pixel(f, fi * npx1 + p, make_float4(r / nn, g / nn, b / nn, al / nn));
+        st_stream(&f.sample_color[fi * spp * npx1 + p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
       }
     } else if (missed) st_stream(&f.sample_color[sid], miss_col);
   }
   if (survive) {
     const uint32_t v = shard * f.shard_cap + slot;
     // (with entry lists the ray carries its tile instead of tmax, which is the constant 10000 of src/shader.rgen:87)
-    st_stream(&f.ray_o[0][v], make_float4(u.position[0], u.position[1], u.position[2], f.entry != nullptr ? __uint_as_float(tile) : 10000.0f));
+    const F3 o = f.batch_k > 1 ? mk3(bt.position[fi][0], bt.position[fi][1], bt.position[fi][2]) : mk3(u.position[0], u.position[1], u.position[2]);
+    st_stream(&f.ray_o[0][v], make_float4(o.x, o.y, o.z, f.entry != nullptr ? __uint_as_float(tile) : 10000.0f));
     st_stream(&f.ray_d[0][v], make_float4(d.x, d.y, d.z, __uint_as_float(sid)));
   }
 }
@@ -1116,7 +1132,7 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
             const uint32_t hdr = (uint32_t)r0.x;
             if (ent == ENTRY_FROM_ROOT) {
               quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
-              sp = 1; cur = a.sc.tlas_root;
+              sp = 1; cur = a.sc.tlas_root + (a.sc.batch_samples ? (int)frame_of(sid, a.sc.batch_samples) * a.sc.tlas_stride : 0);
             } else if (hdr == ENTRY_EMPTY) {
               sp = 1; cur = REF_DONE;   // nothing a ray of this tile can hit: the ray is finished (a miss)
             } else {
@@ -1141,7 +1157,8 @@ __device__ __forceinline__ void trace_body(const TraceArgs& a) {
           } else {
             quant_space(co, cd, a.sc.tlas_q_lo, a.sc.tlas_q_scale, qs, qb, rot); far = FAR && quant_far_o(co, a.sc.tlas_q_lo, a.sc.tlas_q_scale);
             sp = 1;
-            cur = a.sc.tlas_root;   // TLAS root (always interior)
+            cur = a.sc.tlas_root;   // TLAS root (always interior); in a frame batch: the root of the ray's frame
+            if (MODE != MODE_RAW && a.sc.batch_samples) cur += (int)frame_of(sid, a.sc.batch_samples) * a.sc.tlas_stride;
           }
           if (!(CONT && handed_on)) { best_t = (ENTRY && MODE == MODE_CLOSEST) ? 10000.0f : tmax; best_u = 0.f; best_v = 0.f; best_prim = -1; best_inst = -1; }
           need = false;
@@ -1415,14 +1432,16 @@ struct ShadeArgs {
   FrameDev f;
   UniformsDev u;
   int bounce;
+  BatchTab bt;
 };
 
 // TILE: bounce 0 of a frame with tile blobs — the hit records lie in two regions per shard (kernels_tile.inc)
-template <bool TILE = false>
-__device__ __forceinline__ void shade_body(const ShadeArgs& a) {
+// BATCH: the frame is one of a frame batch — the light is the one of the sample's frame (the single-frame instantiations are untouched)
+template <bool TILE = false, bool BATCH = false>
+__device__ __forceinline__ void shade_body(const ShadeArgs& a, const int bounce) {
   const FrameDev& f = a.f;
   const UniformsDev& U = a.u;
-  const int cur = a.bounce & 1, nxt = cur ^ 1;
+  const int cur = bounce & 1, nxt = cur ^ 1;
   const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   // bounce 0 of a frame with tile blobs has its rays in two regions per shard: queue 0 at the bottom, the tile rays (walked by
   // k_trace_tile) at the top — a second pass with the other count and offset
@@ -1436,7 +1455,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
 #pragma unroll
       for (int k = 0; k < BLOB_CLASSES; k++) blobs += ld_cursor(f.counters + cnt_tail(Q_BLOB_LIST + k, t));
       cnt[t] = blobs * (256u * ((U.samples_per_pixel + 3u) / 4u));
-    } else cnt[t] = ld_cursor(f.counters + cnt_tail(a.bounce, t));
+    } else cnt[t] = ld_cursor(f.counters + cnt_tail(bounce, t));
     maxb = max(maxb, (cnt[t] + 63u) >> 6);
   }
   const uint32_t n_waves = gridDim.x * 4u;
@@ -1487,21 +1506,24 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
           M = a.sc.materials + mat;
           if (M->type != TYPE_BY_INSTANCE) type = M->type;
         }
-        const bool last = (uint32_t)a.bounce >= U.max_bounce_count;
+        const bool last = (uint32_t)bounce >= U.max_bounce_count;
         if (type == 0u) {
           // src/shader.rgen:97-131
           if (dot3(d, N) >= 0.0f) {
             st_stream(&f.sample_color[sid], make_float4(0.08f, 0.24f, 0.08f, 1.0f));
           } else {
             no = fma3(0.01f, N, P);
-            const F3 toL = sub3(mk3(U.light_position[0], U.light_position[1], U.light_position[2]), P);
+            F3 light = mk3(U.light_position[0], U.light_position[1], U.light_position[2]);
+            uint32_t fi = 0;   // frame batch: the light of the sample's frame
+            if (BATCH) { fi = frame_of(sid, a.sc.batch_samples); light = mk3(a.bt.light[fi][0], a.bt.light[fi][1], a.bt.light[fi][2]); }
+            const F3 toL = sub3(light, P);
             const float dist = length3(toL);
             const F3 L = mul3(toL, 1.0f / dist);
             const F3 Hh = normalize3(add3(L, neg3(d)));
             const float NdotL = dot3(N, L), NdotH = dot3(N, Hh);
             const float dl = fmaxf(0.0f, NdotL);
             const float sp = M ? pow_int(fmaxf(0.0f, NdotH), (uint32_t)M->ns) : pow100(fmaxf(0.0f, NdotH));
-            const uint32_t i = sid / (uint32_t)(f.rows * f.width);
+            const uint32_t i = sid / (uint32_t)(f.rows * f.width) - fi * U.samples_per_pixel;   // sample index in its pixel
             float w = 1.0f;
             for (uint32_t k = 0; k < i; k++) w = w * 0.9f;
             const float Iv = U.light_intensity;
@@ -1516,7 +1538,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
             if (f.light_entry != nullptr) {
               // which tile of the cube around the light does this ray belong to?  Seen from the light the ray's ORIGIN lies in
               // direction v; the ray then runs to within 0.01 of the light (k_entry's beams are widened by that much).
-              const F3 v = sub3(no, mk3(U.light_position[0], U.light_position[1], U.light_position[2]));
+              const F3 v = sub3(no, light);
               const float ax = __builtin_fabsf(v.x), ay = __builtin_fabsf(v.y), az = __builtin_fabsf(v.z);
               const int axis = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
               const float vc = axis == 0 ? v.x : (axis == 1 ? v.y : v.z), va = axis == 0 ? v.y : (axis == 1 ? v.z : v.x), vb = axis == 0 ? v.z : (axis == 1 ? v.x : v.y);
@@ -1563,7 +1585,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
       }
     }
     // wavefront ballot compaction into the next-bounce queue / the shadow queue of the same shard
-    const uint32_t slot_n = wave_alloc(push_next, f.counters + cnt_tail(a.bounce + 1, (int)shard));
+    const uint32_t slot_n = wave_alloc(push_next, f.counters + cnt_tail(bounce + 1, (int)shard));
     if (push_next) {
       const uint32_t v = shard * f.shard_cap + slot_n;
       st_stream(&f.ray_o[nxt][v], make_float4(no.x, no.y, no.z, 10000.0f));
@@ -1581,8 +1603,8 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a) {
   }
 }
 
-template <bool TILE>
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body<TILE>(a); }
+template <bool TILE, bool BATCH>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body<TILE, BATCH>(a, a.bounce); }
 
 // ------------------------------------------------------------------------------------------------
 // k_tail: bounces first..maxBounceCount of one frame in ONE launch.  After the first bounce a frame usually
@@ -1619,7 +1641,7 @@ __device__ __forceinline__ void grid_barrier(uint32_t* bar, uint32_t* fault, uin
   __syncthreads();
 }
 
-template <bool COUNT, bool WIDE>
+template <bool COUNT, bool WIDE, bool BATCH = false>
 __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
   uint32_t phase = 0;
   const uint32_t max_bounce = t.sh.u.max_bounce_count;
@@ -1637,9 +1659,7 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
     // A barrier that gave up means some workgroup may still be tracing: its hit records are not final, so nobody may
     // shade them.  Every workgroup leaves as soon as it sees the flag (the host re-renders the frame without k_tail).
     if (ld_cursor(t.fault) != 0u) return;
-    ShadeArgs sh = t.sh;
-    sh.bounce = (int)b;
-    shade_body<false>(sh);
+    shade_body<false, BATCH>(t.sh, (int)b);
     grid_barrier(t.barrier, t.fault, phase);
     if (ld_cursor(t.fault) != 0u) return;
   }
@@ -1648,12 +1668,14 @@ __global__ __launch_bounds__(256) void k_tail(TailArgs t) {
 // ------------------------------------------------------------------------------------------------
 // k_resolve: src/shader.rgen:64,180-185 — ordered sum over samples, divide, store.
 __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
-  const uint32_t npx = (uint32_t)(f.rows * f.width);
+  const uint32_t npx1 = (uint32_t)(f.rows * f.width), npx = npx1 * (uint32_t)f.batch_k;   // (a frame batch: the frames back to back)
   const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p < npx && f.sample_color[p].w != PIXEL_DONE) {   // (PIXEL_DONE: every sample of the pixel was a miss and k_raygen stored the pixel)
+  const uint32_t fi = f.batch_k > 1 ? p / npx1 : 0u, p1 = p - fi * npx1;
+  const size_t s0 = (size_t)fi * u.samples_per_pixel * npx1 + p1;   // sample 0 of this pixel
+  if (p < npx && f.sample_color[s0].w != PIXEL_DONE) {   // (PIXEL_DONE: every sample of the pixel was a miss and k_raygen stored the pixel)
     float r = 0.f, g = 0.f, b = 0.f, al = 0.f;
     for (uint32_t i = 0; i < u.samples_per_pixel; i++) {
-      const float4 c = ld_stream(&f.sample_color[(size_t)i * npx + p]);
+      const float4 c = ld_stream(&f.sample_color[s0 + (size_t)i * npx1]);
       r += c.x; g += c.y; b += c.z; al += c.w;
     }
     const float nn = (float)u.samples_per_pixel;
@@ -1713,24 +1735,24 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
 int trace_threads_per_block() { return 256; }
 
 // k_raygen grid: one workgroup per (8x8 tile, group of up to 4 samples)
-static dim3 raygen_grid(int width, int rows, uint32_t spp, dim3& block) {
+static dim3 raygen_grid(int width, int rows, uint32_t spp, int batch_k, dim3& block) {
   const uint32_t wpb = spp < 4u ? spp : 4u;
   block = dim3(64, wpb);
-  return dim3(((uint32_t)width + 7u) >> 3, ((uint32_t)rows + 7u) >> 3, (spp + wpb - 1u) / wpb);
+  return dim3(((uint32_t)width + 7u) >> 3, (((uint32_t)rows + 7u) >> 3) * (uint32_t)batch_k, (spp + wpb - 1u) / wpb);
 }
-size_t raygen_block_count(int width, int rows, uint32_t spp) {
-  dim3 b; const dim3 g = raygen_grid(width, rows, spp, b);
+size_t raygen_block_count(int width, int rows, uint32_t spp, int batch_k) {
+  dim3 b; const dim3 g = raygen_grid(width, rows, spp, batch_k, b);
   return (size_t)g.x * g.y * g.z;
 }
-void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s) {
-  dim3 b; const dim3 g = raygen_grid(f.width, f.rows, u.samples_per_pixel, b);
-  hipLaunchKernelGGL(k_raygen, g, b, 0, s, sc, f, u);
+void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, hipStream_t s) {
+  dim3 b; const dim3 g = raygen_grid(f.width, f.rows, u.samples_per_pixel, f.batch_k, b);
+  hipLaunchKernelGGL(k_raygen, g, b, 0, s, sc, f, u, bt);
 }
 size_t jitter_table_elems(int width, int rows, uint32_t spp) {
   return (size_t)(((uint32_t)width + 7u) >> 3) * (size_t)(((uint32_t)rows + 7u) >> 3) * spp * 64u;
 }
 void launch_jitter_table(const FrameDev& f, uint32_t spp, float2* table, hipStream_t s) {
-  dim3 b; const dim3 g = raygen_grid(f.width, f.rows, spp, b);
+  dim3 b; const dim3 g = raygen_grid(f.width, f.rows, spp, 1, b);
   hipLaunchKernelGGL(k_jitter_table, g, b, 0, s, f, spp, table);
 }
 
@@ -1920,12 +1942,12 @@ int tail_blocks_per_cu() {
   return n;
 }
 
-void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s) {
+void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s) {
   TailArgs t{};
   t.tr = make_args(sc, f.counters, first_bounce, f.shard_cap, f.ovf_stack);
   t.tr.hit_a = f.hit_a; t.tr.hit_inst = f.hit_inst;
   t.tr.rays_per_lane = 1u; t.tr.min_blocks = 8u;   // few rays: one per lane, the bounce costs one ray lifetime
-  t.sh = ShadeArgs{sc, f, u, first_bounce};
+  t.sh = ShadeArgs{sc, f, u, first_bounce, bt};
   t.first_bounce = (uint32_t)first_bounce;
   t.barrier = f.counters + CNT_BARRIER; t.fault = f.counters + CNT_FAULT;
   const dim3 g((unsigned)tail_blocks), b(256);
@@ -1936,14 +1958,20 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, in
     return;
   }
 #endif
+  if (f.batch_k > 1) {
+    if (counting) hipLaunchKernelGGL((k_tail<true, false, true>), g, b, 0, s, t);
+    else hipLaunchKernelGGL((k_tail<false, false, true>), g, b, 0, s, t);
+    return;
+  }
   if (counting) hipLaunchKernelGGL((k_tail<true, false>), g, b, 0, s, t);
   else hipLaunchKernelGGL((k_tail<false, false>), g, b, 0, s, t);
 }
 
-void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s) {
-  ShadeArgs a{sc, f, u, bounce};
-  if (bounce == 0 && f.tile_blob != nullptr) hipLaunchKernelGGL((k_shade<true>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((k_shade<false>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int bounce, const LaunchCfg& cfg, hipStream_t s) {
+  ShadeArgs a{sc, f, u, bounce, bt};
+  if (f.batch_k > 1) hipLaunchKernelGGL((k_shade<false, true>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+  else if (bounce == 0 && f.tile_blob != nullptr) hipLaunchKernelGGL((k_shade<true, false>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((k_shade<false, false>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1969,7 +1997,7 @@ void launch_assemble(const void* gathered, void* out, int width, int height, int
 }
 
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s) {
-  const uint32_t npx = (uint32_t)(f.rows * f.width);
+  const uint32_t npx = (uint32_t)(f.rows * f.width) * (uint32_t)f.batch_k;
   hipLaunchKernelGGL(k_resolve, dim3((npx + 255u) / 256u), dim3(256), 0, s, f, u);
 }
 

@@ -141,6 +141,13 @@ struct rt_ctx {
   size_t cap_inst[2] = {0, 0};
   int parity = 0;
   int tlas_node_count[2] = {0, 0};   // nodes of the TLAS uploaded for that parity
+  // frame batch (rt_set_batch / rt_trace_shard_batch): batch_k frames go through one pass of the pipeline; h_inst then holds the
+  // instances of all of them (frame k's at k * inst_per_frame), batch_uni their uniform blocks, and the slot's TLAS region their trees,
+  // tlas_stride[parity] nodes apart, in one quantisation
+  int batch_k = 1;
+  int inst_per_frame = 0;
+  int tlas_stride[2] = {0, 0};
+  std::vector<UniformsDev> batch_uni;
   hipEvent_t ev_frame[2] = {nullptr, nullptr};   // end of the last frame that read the buffers of that parity
   bool ev_frame_valid[2] = {false, false};
   float tlas_q_lo[3] = {0, 0, 0}, tlas_q_scale[3] = {1, 1, 1};
@@ -229,7 +236,7 @@ struct rt_ctx {
   // what the last enqueued frame was rendered from: a re-render after a k_tail fault must produce THAT frame, whatever
   // rt_set_uniforms / rt_set_instances did since (the instance records and TLAS nodes of `parity` are still the frame's own
   // as long as inst_gen[parity] has not moved: one later rt_set_instances writes the other parity)
-  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; } last_frame{};
+  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; int batch_k; BatchTab bt; } last_frame{};
   uint64_t inst_gen[2] = {0, 0};  // bumped whenever the records of that parity are rewritten
   // shadow_entry 2: the records of the cube around the light depend on the light, the instances and the trees only — like the TLAS they are
   // kept while those stand still: built in a context's first frame and in the second consecutive frame with a new key, used from then on, dropped when the key moves
@@ -528,12 +535,32 @@ inline size_t tlas_base4(const rt_ctx* c) { return c->scene->n_blas4 + (size_t)(
 // Instance records and this slot's TLAS nodes go to the device WITHOUT stalling the host: they are assembled in pinned
 // memory and copied on the context's stream; ev_upload orders frames on other streams behind the copies.  (The reference
 // allocates two buffers, submits and blocks on vkWaitForFences every frame, src/main.cpp:672-696, 752-778.)
-int upload_instances(rt_ctx* c, const std::vector<InstanceDev>& inst_dev) {
+// frame_trees: the TLAS of every frame of a batch (same topology, refitted to that frame's boxes); NULL = the one tree c->tlas
+int upload_instances(rt_ctx* c, const std::vector<InstanceDev>& inst_dev, const std::vector<BuiltBvh>* frame_trees = nullptr) {
   Scene* S = c->scene;
   const size_t n = inst_dev.size();
   std::vector<BvhNodeQ> tq;
-  quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
-  c->tlas_node_count[c->parity] = (int)tq.size();
+  size_t stride = 0;
+  if (frame_trees == nullptr) quantize_bvh2(c->tlas, tq, c->tlas_q_lo, c->tlas_q_scale);
+  else {
+    // one quantisation for all frames (the kernels carry ONE world-space dequantisation), the trees one after another
+    double lo[3] = {3e38, 3e38, 3e38}, hi[3] = {-3e38, -3e38, -3e38};
+    for (const BuiltBvh& t : *frame_trees) bvh2_bounds(t, lo, hi);
+    quant_params(lo, hi, c->tlas_q_lo, c->tlas_q_scale);
+    const size_t per_frame = inst_dev.size() / frame_trees->size();
+    for (size_t k = 0; k < frame_trees->size(); k++) {
+      std::vector<BvhNodeQ> one;
+      quantize_bvh2_in((*frame_trees)[k], one, c->tlas_q_lo, c->tlas_q_scale);
+      if (k == 0) stride = one.size();
+      for (BvhNodeQ& nd : one) {   // links local to the frame's tree -> local to the slot's region; leaves name the frame's own instance records
+        if (nd.child0 >= 0) nd.child0 += (int32_t)(k * stride); else nd.child0 = ~(int32_t)((uint32_t)(~nd.child0) + (uint32_t)(k * per_frame));
+        if (nd.child1 >= 0) nd.child1 += (int32_t)(k * stride); else nd.child1 = ~(int32_t)((uint32_t)(~nd.child1) + (uint32_t)(k * per_frame));
+      }
+      tq.insert(tq.end(), one.begin(), one.end());
+    }
+  }
+  c->tlas_node_count[c->parity] = (int)(frame_trees ? stride : tq.size());
+  c->tlas_stride[c->parity] = frame_trees ? (int)stride : 0;
   const size_t need = std::max(tq.size(), c->tlas4.nodes.size());
   if (need > S->tlas_cap) {
     // a sole owner may grow the regions (nothing else reads the arrays); with several slots the arrays cannot move
@@ -594,6 +621,7 @@ SceneDev scene_dev(const rt_ctx* c) {
   s.nodes4 = S->d_nodes4; s.tlas_root4 = (int)tlas_base4(c);
   s.wide_nodes = S->d_wide; s.ovf_stride = c->ovf_stride;
   s.tlas_nodes = c->tlas_node_count[c->parity];
+  s.tlas_stride = c->batch_k > 1 ? c->tlas_stride[c->parity] : 0;
   s.blas_nodes = S->d_blas_nodes; s.tlas_root = (int)tlas_base(c); s.tris = S->d_tris; s.inst = c->d_inst[c->parity];
   s.verts = S->d_verts; s.idx = S->d_idx; s.sky = S->d_sky; s.n_inst = (int)c->h_inst.size();
   s.sky_w = S->sky_w; s.sky_h = S->sky_h;
@@ -661,9 +689,10 @@ int quiesce_scene(rt_ctx* c) {
 // the linked arrays changed: every slot has to set its instances again
 void invalidate_tlas(Scene* S) { for (rt_ctx* m : S->members) m->tlas_valid = false; }
 
-int ready_to_trace(rt_ctx* c) {
+int ready_to_trace(rt_ctx* c, bool batch = false) {
   if (!c->scene->d_verts) return fail(c, RT_ERR_NOT_READY, "rt_upload_geometry has not been called");
   if (!c->tlas_valid) return fail(c, RT_ERR_NOT_READY, "rt_set_instances has not been called");
+  if (!batch && c->batch_k != 1) return fail(c, RT_ERR_NOT_READY, "the context holds a frame batch (rt_set_batch): render it with rt_trace_shard_batch, or call rt_set_instances for a single frame");
   return RT_OK;
 }
 
@@ -775,21 +804,34 @@ struct Span {
 
 // `again`: render THIS frame once more (after a k_tail fault) from the state it was submitted with, without k_tail
 int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, float4* d_out, hipStream_t s, const rt_ctx::LastFrame* again = nullptr) {
-  const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
+  const int rows = rt_shard_rows(H, band_rows, shard, n_shards);   // of ONE frame's shard
   const bool no_tail = again != nullptr;
-  const SceneDev sc = again ? again->sc : scene_dev(c);
+  // frame batch: K frames (their instance records and TLAS trees are in place: rt_set_batch) go through this one pass
+  const int K = again ? again->batch_k : c->batch_k;
+  SceneDev sc = again ? again->sc : scene_dev(c);
   const UniformsDev u = again ? again->uni : c->uni;
+  BatchTab bt{};
+  if (again) bt = again->bt;
+  else if (K > 1)
+    for (int k = 0; k < K; k++) {
+      const UniformsDev& uk = c->batch_uni[k];
+      for (int j = 0; j < 4; j++) { bt.position[k][j] = uk.position[j]; bt.right[k][j] = uk.right[j]; bt.up[k][j] = uk.up[j]; bt.forward[k][j] = uk.forward[j]; }
+      for (int j = 0; j < 3; j++) bt.light[k][j] = uk.light_position[j];
+    }
+  if (K > 1) sc.batch_samples = (uint32_t)((size_t)u.samples_per_pixel * (size_t)rows * (size_t)W);
+  const int n_inst1 = K > 1 ? sc.n_inst / K : sc.n_inst;   // instances of one frame
   const int frame_parity = again ? again->parity : c->parity;
-  if (!again) { c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting, sc, u, c->parity, c->inst_gen[c->parity]}; c->frame_rerendered = false; }
+  if (!again) { c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting, sc, u, c->parity, c->inst_gen[c->parity], K, bt}; c->frame_rerendered = false; }
   if (u.samples_per_pixel == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "samplesPerPixel must be >= 1");
   if (u.max_bounce_count + 2 > (uint32_t)CNT_MAX_BOUNCES) return fail(c, RT_ERR_INVALID_ARGUMENT, "maxBounceCount too large (max 69)");
-  const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8);
+  const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8) * (size_t)K;
   const size_t samples = tiles * u.samples_per_pixel * 64;   // k_raygen threads
   if (samples >= 0xF0000000ull) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for 32-bit sample ids");
   if (rows > 8 * 65535 || u.samples_per_pixel > 4u * 65535u) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame too large for the raygen grid");
   // k_raygen block b appends to shard b % 8, so a shard never receives more than this many rays; paths
   // stay in their shard, so the bound holds for every later queue as well
-  const size_t raygen_blocks = raygen_block_count(W, rows, u.samples_per_pixel);
+  if ((size_t)rows * K > 8u * 65535u) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame batch too tall for the raygen grid");
+  const size_t raygen_blocks = raygen_block_count(W, rows, u.samples_per_pixel, K);
   // (with tile blobs a shard also holds the tile region — a fixed 256 slots per blob and group of four samples, whether a ray fills
   // them or not — while the rays k_tile hands on, at most as many again, go to queue 0 of the same shard; and k_tile sends ALL sample
   // groups of a tile to shard tile % 8 where k_raygen spreads them: twice the room covers both)
@@ -802,6 +844,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   f.ovf_stack = c->d_ovf; f.out = d_out; f.out_rgba8 = c->out_rgba8 ? (c->out_bgra ? 2 : 1) : 0; f.hint = c->d_hint; f.stats_out = c->d_stats; f.fault_total = c->d_fault_total;
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
+  f.batch_k = K;
   // Primary-ray coverage mask: on when the bands are whole 8x8 tiles, the camera basis is invertible and the scene has boxes.
   // The mask of this frame was cleared by the previous frame's k_resolve (or at allocation); this frame's clears the other.
   // Views: 0 = the camera; 1..6 = the faces of a cube around the light, when the shadow rays take entry lists (below).
@@ -809,41 +852,52 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   CoverArgs& ca = cv.v[0];
   bool cover_on = c->primary_cover && rows > 0 && c->scene->max_cover_count > 0 && (n_shards == 1 || band_rows % 8 == 0) && c->cfg.variant != 1 &&
                   sc.n_inst <= 65535;   // (k_cover's grid has one row of workgroups per instance)
-  if (cover_on) {
-    const double R[9] = {u.right[0], u.up[0], u.forward[0], u.right[1], u.up[1], u.forward[1], u.right[2], u.up[2], u.forward[2]};   // columns right, up, forward
+  const uint32_t cam_words = 1u + (uint32_t)((((size_t)((W + 7) / 8) * (size_t)((H + 7) / 8)) + 31) / 32);   // one camera view's mask
+  // (a frame batch: every frame is a view of its own — its camera, its instance records, its part of the mask block)
+  auto camera_view = [&](const float* position, const float* right, const float* up, const float* forward, CoverArgs& a) -> bool {
+    const double R[9] = {right[0], up[0], forward[0], right[1], up[1], forward[1], right[2], up[2], forward[2]};   // columns right, up, forward
     const double det = R[0] * (R[4] * R[8] - R[5] * R[7]) - R[1] * (R[3] * R[8] - R[5] * R[6]) + R[2] * (R[3] * R[7] - R[4] * R[6]);
     const double scale = std::fabs(R[0]) + std::fabs(R[1]) + std::fabs(R[2]) + std::fabs(R[3]) + std::fabs(R[4]) + std::fabs(R[5]) + std::fabs(R[6]) + std::fabs(R[7]) + std::fabs(R[8]);
-    if (!(std::fabs(det) > 1e-6 * scale * scale * scale / 27.0) || !std::isfinite(det)) cover_on = false;
+    if (!(std::fabs(det) > 1e-6 * scale * scale * scale / 27.0) || !std::isfinite(det)) return false;
+    const double id = 1.0 / det;
+    const double inv[9] = {(R[4] * R[8] - R[5] * R[7]) * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
+                           (R[5] * R[6] - R[3] * R[8]) * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
+                           (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
+    for (int k = 0; k < 9; k++) a.inv[k] = (float)inv[k];
+    for (int k = 0; k < 3; k++) a.cam[k] = position[k];
+    a.kf = 2.5f;   // src/shader.rgen:79
+    a.width = W; a.height = H; a.tiles_x = (W + 7) / 8; a.tiles_y = (H + 7) / 8; a.n_inst = n_inst1;
+    a.mask_offset = 0; a.apex_radius = 0.0f; a.inst_base = 0;
+    return true;
+  };
+  if (cover_on) {
+    if (K == 1) { cover_on = camera_view(u.position, u.right, u.up, u.forward, ca); cv.n = 1; }
     else {
-      const double id = 1.0 / det;
-      const double inv[9] = {(R[4] * R[8] - R[5] * R[7]) * id, (R[2] * R[7] - R[1] * R[8]) * id, (R[1] * R[5] - R[2] * R[4]) * id,
-                             (R[5] * R[6] - R[3] * R[8]) * id, (R[0] * R[8] - R[2] * R[6]) * id, (R[2] * R[3] - R[0] * R[5]) * id,
-                             (R[3] * R[7] - R[4] * R[6]) * id, (R[1] * R[6] - R[0] * R[7]) * id, (R[0] * R[4] - R[1] * R[3]) * id};
-      for (int k = 0; k < 9; k++) ca.inv[k] = (float)inv[k];
-      for (int k = 0; k < 3; k++) ca.cam[k] = u.position[k];
-      ca.kf = 2.5f;   // src/shader.rgen:79
-      ca.width = W; ca.height = H; ca.tiles_x = (W + 7) / 8; ca.tiles_y = (H + 7) / 8; ca.n_inst = sc.n_inst;
-      ca.mask_offset = 0; ca.apex_radius = 0.0f;
-      cv.n = 1;
+      for (int k = 0; k < K && cover_on; k++) {
+        cover_on = camera_view(bt.position[k], bt.right[k], bt.up[k], bt.forward[k], cv.v[k]);
+        cv.v[k].mask_offset = (uint32_t)k * cam_words; cv.v[k].inst_base = k * n_inst1;
+      }
+      cv.n = K;
     }
+    if (!cover_on) cv.n = 0;
   }
   // Entry lists (k_entry) ride on the coverage mask: same tiles, same camera basis; the one-lane BVH2 kernel only.
   // (a record opens ONE instance's BLAS; where the beam of a tile meets many instances — cfg5's ring of 16 — the TLAS phase of k_entry costs
   // more than the records save: measured 1.86 vs 1.80 ms per frame, profiles/r03_experiments.txt — so records are for scenes of few instances)
-  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && sc.n_inst <= c->entry_max_instances;
+  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && n_inst1 <= c->entry_max_instances;
   // far-ray logic in this frame's kernels only if some ray can be far (a re-render does not trust the context's current instance list: it carries the logic)
-  const bool far_frame = again != nullptr || far_possible(c, u);
+  bool far_frame = again != nullptr || far_possible(c, u);
+  for (int k = 1; k < K && !far_frame; k++) far_frame = far_possible(c, c->batch_uni[k]);   // (against the instances of ALL frames: conservative)
   // ... and the tiles' blobs on the records (no far-ray logic in the LDS walk: such frames keep the global walk)
-  const bool tile_on = entry_on && c->tile_blobs && !far_frame;
+  const bool tile_on = entry_on && c->tile_blobs && !far_frame && K == 1;
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
   // (kept records are paid once, so they also serve scenes of more instances than the per-frame camera records are worth building for)
-  const bool light_on = cover_on && c->entry_points && c->cfg.variant == 0 && (entry_on || c->shadow_entry == 2) && c->shadow_entry &&
+  const bool light_on = K == 1 && cover_on && c->entry_points && c->cfg.variant == 0 && (entry_on || c->shadow_entry == 2) && c->shadow_entry &&
                         std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2]);
   const int LT = c->light_tiles;
-  const uint32_t cam_words = 1u + (uint32_t)((((size_t)((W + 7) / 8) * (size_t)((H + 7) / 8)) + 31) / 32);
   const uint32_t face_words = 1u + (uint32_t)(((size_t)LT * LT + 31) / 32);
   {
-    const uint32_t words = cam_words + 6u * face_words;
+    const uint32_t words = std::max(cam_words + 6u * face_words, (uint32_t)K * cam_words);
     if (cover_on && words > c->cover_alloc_words) {
       if (c->d_cover_mask) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_cover_mask)); c->d_cover_mask = nullptr; c->cover_alloc_words = 0; }
       HIP_TRY(c, hipMalloc((void**)&c->d_cover_mask, 2 * (size_t)words * sizeof(uint32_t)));
@@ -856,15 +910,15 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
     // (a frame that does not use the mask still clears the next one, so that a later frame finds it clean)
     f.cover = cover_on ? c->d_cover_mask + (size_t)c->cover_parity * c->cover_alloc_words : nullptr;
     f.cover_next = c->d_cover_mask + (size_t)(c->cover_parity ^ 1) * c->cover_alloc_words;
-    f.cover_words = c->cover_alloc_words; f.cover_tiles_x = (W + 7) / 8;
+    f.cover_words = c->cover_alloc_words; f.cover_tiles_x = (W + 7) / 8; f.cover_view_words = cam_words;
   }
   EntryViews ev{};
   if ((entry_on || light_on) && f.cover != nullptr) {
-    const size_t tiles_local = entry_on ? (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8) : 0;
-    if (tiles_local > c->entry_alloc_tiles) {
+    const size_t tiles_local = entry_on ? (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8) : 0;   // of one frame
+    if (tiles_local * K > c->entry_alloc_tiles) {
       if (c->d_entry) { HIP_TRY(c, hipStreamSynchronize(c->stream)); if (s != c->stream) HIP_TRY(c, hipStreamSynchronize(s)); HIP_TRY(c, hipFree(c->d_entry)); c->d_entry = nullptr; c->entry_alloc_tiles = 0; }
-      HIP_TRY(c, hipMalloc((void**)&c->d_entry, tiles_local * sizeof(EntryRec)));
-      c->entry_alloc_tiles = tiles_local;
+      HIP_TRY(c, hipMalloc((void**)&c->d_entry, tiles_local * K * sizeof(EntryRec)));
+      c->entry_alloc_tiles = tiles_local * K;
     }
     f.entry = entry_on ? c->d_entry : nullptr;
     if (tile_on) {
@@ -885,17 +939,22 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       }
       f.tile_blob = c->d_tile_blob; f.blob_arena = c->d_blob_arena; f.blob_slots = c->blob_slots; f.blob_list = c->d_blob_list;
     }
-    EntryArgs& ea = ev.v[0];   // (without camera records view 0 stays empty: no tiles, no blocks with work)
-    if (entry_on) {
-    for (int k = 0; k < 3; k++) ea.cam[k] = ca.cam[k];
-    for (int k = 0; k < 9; k++) ea.inv[k] = ca.inv[k];
-    for (int k = 0; k < 3; k++) { ea.basis[k] = u.right[k]; ea.basis[3 + k] = u.up[k]; ea.basis[6 + k] = u.forward[k]; }
-    ea.kf = 2.5f; ea.apex_radius = 0.0f;
-    ea.width = W; ea.height = H; ea.tiles_x = (W + 7) / 8; ea.tile_rows = (rows + 7) / 8;
-    ea.band_rows = band_rows; ea.shard = shard; ea.n_shards = n_shards;
-    ea.records = c->d_entry; ea.cover = f.cover; ea.cover_tiles_x = f.cover_tiles_x;
-    }
-    ev.n = 1;
+    // (without camera records view 0 stays empty: no tiles, no blocks with work; a frame batch: one view per frame)
+    if (entry_on)
+      for (int fk = 0; fk < K; fk++) {
+        EntryArgs& ea = ev.v[fk];
+        const CoverArgs& cak = cv.v[fk];
+        const float* right = K > 1 ? bt.right[fk] : u.right; const float* up = K > 1 ? bt.up[fk] : u.up; const float* fwd = K > 1 ? bt.forward[fk] : u.forward;
+        for (int k = 0; k < 3; k++) ea.cam[k] = cak.cam[k];
+        for (int k = 0; k < 9; k++) ea.inv[k] = cak.inv[k];
+        for (int k = 0; k < 3; k++) { ea.basis[k] = right[k]; ea.basis[3 + k] = up[k]; ea.basis[6 + k] = fwd[k]; }
+        ea.kf = 2.5f; ea.apex_radius = 0.0f;
+        ea.width = W; ea.height = H; ea.tiles_x = (W + 7) / 8; ea.tile_rows = (rows + 7) / 8;
+        ea.band_rows = band_rows; ea.shard = shard; ea.n_shards = n_shards;
+        ea.records = c->d_entry + (size_t)fk * tiles_local; ea.cover = f.cover + (size_t)fk * cam_words; ea.cover_tiles_x = f.cover_tiles_x;
+        ea.tlas_root_offset = fk * sc.tlas_stride;
+      }
+    ev.n = entry_on ? K : 1;
     if (light_on) {
       const size_t light_tiles_total = (size_t)6 * LT * LT;
       if (light_tiles_total > c->light_alloc_tiles) {
@@ -953,7 +1012,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (c->timing) c->timed_frames++;
   c->frame_stream = s; c->frame_pending = true;
   c->last_max_bounce = u.max_bounce_count;
-  c->last_primary = (uint64_t)W * rows * u.samples_per_pixel;
+  c->last_primary = (uint64_t)W * rows * u.samples_per_pixel * (uint64_t)K;
   c->last_empty = rows == 0;
   // the instance records / TLAS nodes of this slot were copied on the context's stream: a frame on another stream waits on the device
   if (c->upload_pending && s != c->stream) HIP_TRY(c, hipStreamWaitEvent(s, c->ev_upload[c->parity], 0));   // (also orders a re-render behind newer uploads: harmless)
@@ -975,7 +1034,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       if (f.cover) launch_cover(sc, cv, c->scene->max_cover_count, const_cast<uint32_t*>(f.cover), s);
       if (f.entry || ev.n > 1) launch_entry(sc, ev, s);
       if (f.tile_blob) launch_blob(sc, ev.v[0], f, c->counting, s);
-      launch_raygen(sc, f, u, s);
+      launch_raygen(sc, f, u, bt, s);
     }
     // k_tail takes over at the first bounce whose queue was small in the previous frame of this context (a hint:
     // either strategy gives the same image); bounces before it run on the full persistent grid
@@ -994,7 +1053,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
         // mostly waits (1/8 shard with 16 slots in flight: 0.100 ms with 64 workgroups, 0.091 with 8, 0.088 with 2)
         // (contexts created since — other scenes on this GPU included — shrink every slot's share of the resident workgroups)
         int tb = std::min(c->tail_blocks, tail_grid(c->n_cu, c->tail_resident_per_cu, live_slots_on(c->device)));
-        if (tb <= 0) { { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cfg, s); } { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); } continue; }
+        if (tb <= 0) { { Span sp(c, CAT_TRACE, s); launch_trace_closest(sc, f, (int)b, c->counting, cfg, s); } { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, bt, (int)b, cfg, s); } continue; }
         const uint32_t expect = ((volatile uint32_t*)c->h_hint)[b];
         // (a lone slot keeps the full grid: nobody else needs the room and 64 workgroups finish 2 k rays in 43 us, 9 in 55)
         if (c->tail_mode == 1 && expect != 0xFFFFFFFFu && !c->tail_full_grid && c->scene->members.size() >= 3) {
@@ -1003,14 +1062,14 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
           if (lo >= N_SHARDS) want = (want + (N_SHARDS - 1)) / N_SHARDS * N_SHARDS;
           tb = (int)std::min<long>(tb, std::max<long>(lo, want));
         }
-        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, (int)b, c->counting, cfg, tb, s);
+        Span sp(c, CAT_TAIL, s); launch_tail(sc, f, u, bt, (int)b, c->counting, cfg, tb, s);
         break;
       }
       { LaunchCfg cc = cfg; if (b == 0 && cap_closest > 0) cc.trace_blocks = std::min(cfg.trace_blocks, c->n_cu * cap_closest);
         Span sp(c, CAT_TRACE, s);
         if (b == 0 && f.tile_blob) launch_tile(sc, f, u, c->counting, s);   // the tiles with a blob: their rays generated and walked in LDS (it hands a few on to queue 0)
         launch_trace_closest(sc, f, (int)b, c->counting, cc, s); }
-      { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, (int)b, cfg, s); }
+      { Span sp(c, CAT_SHADE, s); launch_shade(sc, f, u, bt, (int)b, cfg, s); }
       if (b >= 7 && (b & 3) == 3 && b < u.max_bounce_count) {
         // deep bounce budgets (the reference default is 63): stop launching once every path has ended
         uint32_t tails[N_SHARDS * CNT_STRIDE];
@@ -1298,7 +1357,8 @@ int rt_build_blas(rt_ctx* c, int mesh) {
   return RT_OK;
 }
 
-int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
+// the instances of K frames (K = 1: rt_set_instances; K > 1: a frame batch, frame k's n instances at inst + k * n)
+static int set_instances_frames(rt_ctx* c, const rt_instance* inst, int n, int update, int K) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (!inst || n <= 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "no instances");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1308,12 +1368,14 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   const int next_parity = c->parity ^ 1;
   if (c->ev_frame_valid[next_parity]) { HIP_TRY(c, hipEventSynchronize(c->ev_frame[next_parity])); c->ev_frame_valid[next_parity] = false; }
   if (c->upload_inflight[next_parity]) { HIP_TRY(c, hipEventSynchronize(c->ev_upload[next_parity])); c->upload_inflight[next_parity] = false; }   // its staging buffer is rewritten
-  for (int i = 0; i < n; i++) {
+  const int total = n * K;
+  for (int i = 0; i < total; i++) {
     if (inst[i].mesh >= S->meshes.size()) return fail(c, RT_ERR_INVALID_ARGUMENT, "instance references an unknown mesh");
     if (!S->meshes[inst[i].mesh].built) return fail(c, RT_ERR_NOT_READY, "instance references a mesh whose BLAS is not built (rt_build_blas)");
   }
-  if (update && (!c->tlas_valid || (int)c->h_inst.size() != n))
+  if (update && (!c->tlas_valid || c->inst_per_frame != n))
     return fail(c, RT_ERR_INVALID_ARGUMENT, "TLAS update needs a previous build with the same instance count");
+  if (K > 1 && c->cfg.variant != 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "frame batches need trace_variant 0");
   if (!S->blas_linked) {   // (re)linking moves the shared arrays: every slot of the scene has to be idle
     int q = quiesce_scene(c); if (q) return q;
     int r = link_blas(c); if (r) return r;
@@ -1321,10 +1383,10 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
   // from here on the slot's host-side TLAS state is being replaced: an error return leaves it INVALID (rt_set_instances
   // has to be called again) instead of half old, half new
   c->tlas_valid = false;
-  c->h_inst.assign(inst, inst + n);
-  std::vector<InstanceDev> inst_dev(n);
-  std::vector<Aabb> boxes(n);
-  for (int i = 0; i < n; i++) {
+  c->h_inst.assign(inst, inst + total);
+  std::vector<InstanceDev> inst_dev(total);
+  std::vector<Aabb> boxes(total);
+  for (int i = 0; i < total; i++) {
     InstanceDev& d = inst_dev[i];
     const Mesh& m = S->meshes[inst[i].mesh];
     memcpy(d.o2w, inst[i].transform, sizeof(d.o2w));
@@ -1336,15 +1398,22 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
     d.custom_index = (int32_t)(inst[i].custom_index_and_mask & 0xFFFFFFu);
     d.first_float = (uint32_t)m.range.first_float;
     d.first_index = (uint32_t)m.range.first_index;
-    d.type = (size_t)i < c->inst_types.size() ? c->inst_types[i] : TYPE_BY_OBJECT_INDEX;
+    d.type = (size_t)(i % n) < c->inst_types.size() ? c->inst_types[i % n] : TYPE_BY_OBJECT_INDEX;
     d.cover_first = m.cover_first; d.cover_count = m.range.prim_count ? m.cover_count : 0u; d.pad = 0;
     boxes[i] = instance_world_box(d.o2w, m.bounds);
   }
+  // frame 0 builds (or refits) the context's TLAS; the other frames of a batch are refits of that topology to their own boxes
+  std::vector<BuiltBvh> frame_trees;
   if (update) { refit_bvh(boxes.data(), c->tlas); refit_bvh4(c->tlas, c->tlas4); }
   else { build_bvh(boxes.data(), (uint32_t)n, 1, 20, c->tlas); collapse_bvh4(c->tlas, false, true, c->tlas4); }
+  if (K > 1) {
+    frame_trees.resize(K);
+    frame_trees[0] = c->tlas;
+    for (int k = 1; k < K; k++) { frame_trees[k] = c->tlas; refit_bvh(boxes.data() + (size_t)k * n, frame_trees[k]); }
+  }
   // the quad traversal keeps its whole stack in LDS: bottom sentinel + TLAS + marker + deepest BLAS
   int blas_need = 0, blas_levels = 0;
-  for (int i = 0; i < n; i++) {
+  for (int i = 0; i < total; i++) {
     const Mesh& m = S->meshes[inst[i].mesh];
     if (m.gpu_built && c->cfg.variant == 1) return fail(c, RT_ERR_INVALID_ARGUMENT, "device-built BLAS is not traversed by trace_variant 1: set trace_variant before rt_build_blas or use blas_builder 0");
     blas_need = std::max(blas_need, m.bvh4.stack_need);
@@ -1363,10 +1432,30 @@ int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) {
                     " traversal-stack entries, more than the " + std::to_string((int)STACK4_LDS) + " the kernel keeps in LDS");
   c->parity = next_parity;
   c->inst_gen[next_parity]++;
-  int r = upload_instances(c, inst_dev); if (r) return r;
+  c->inst_per_frame = n; c->batch_k = K;
+  int r = upload_instances(c, inst_dev, K > 1 ? &frame_trees : nullptr); if (r) return r;
   c->tlas_valid = true;
   return RT_OK;
 }
+
+int rt_set_instances(rt_ctx* c, const rt_instance* inst, int n, int update) { return set_instances_frames(c, inst, n, update, 1); }
+
+int rt_set_batch(rt_ctx* c, int n_frames, const rt_instance* instances, int n, const rt_uniforms* uniforms, int update) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (n_frames < 1 || n_frames > BATCH_MAX) return fail(c, RT_ERR_INVALID_ARGUMENT, "a batch holds 1.." + std::to_string((int)BATCH_MAX) + " frames");
+  if (!uniforms) return fail(c, RT_ERR_INVALID_ARGUMENT, "no uniforms");
+  static_assert(sizeof(rt_uniforms) == sizeof(UniformsDev), "rt_uniforms layout");
+  for (int k = 1; k < n_frames; k++)
+    if (uniforms[k].max_bounce_count != uniforms[0].max_bounce_count || uniforms[k].samples_per_pixel != uniforms[0].samples_per_pixel ||
+        uniforms[k].center_object_type != uniforms[0].center_object_type || uniforms[k].orbiting_object_type != uniforms[0].orbiting_object_type)
+      return fail(c, RT_ERR_INVALID_ARGUMENT, "the frames of a batch share maxBounceCount, samplesPerPixel and the object types (camera, light and instances may differ)");
+  int r = set_instances_frames(c, instances, n, update, n_frames); if (r) return r;
+  c->batch_uni.resize(n_frames);
+  memcpy(c->batch_uni.data(), uniforms, (size_t)n_frames * sizeof(UniformsDev));
+  c->uni = c->batch_uni[0]; c->have_uni = true;
+  return RT_OK;
+}
+
 
 // Row n4: the MTL materials the reference's loader parses and its renderer ignores (src/shader.rgen:51-55
 // hard-codes kd, ks, 100, 1.52).  table[prim_material[g]] shades triangle g of the index buffer (g = first_index / 3 +
@@ -1638,6 +1727,21 @@ int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shar
 // Root-side step of a multi-GPU frame: n_shards compact shards (as rt_trace_shard writes them, each padded to
 // shard_stride_bytes) lie back to back in d_gathered after the gather; this writes the width x height frame to d_frame on
 // hip_stream (NULL = the context's stream).  Pixel format = the context's ("output_rgba8").  Asynchronous.
+int rt_trace_shard_batch(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t out_capacity_bytes, void* hip_stream) {
+  if (!c) return RT_ERR_INVALID_ARGUMENT;
+  if (W <= 0 || H <= 0 || band_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !d_out)
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace_shard_batch arguments");
+  if (!c->have_uni) return fail(c, RT_ERR_NOT_READY, "rt_set_batch has not been called");
+  if (c->async_pending) return fail(c, RT_ERR_NOT_READY, "a frame submitted with rt_trace_async is pending: call rt_trace_wait first");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int r = ready_to_trace(c, true); if (r) return r;
+  const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
+  if ((size_t)rows * W * (c->out_rgba8 ? 4 : 16) * (size_t)c->batch_k > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for the shards of this batch");
+  hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+  if (c->frame_pending && c->frame_stream != s) { int q = collect_stats(c); if (q) return q; }
+  return enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
+}
+
 int rt_assemble_shards(rt_ctx* c, const void* d_gathered, int n_shards, size_t shard_stride_bytes, int W, int H, int band_rows,
                        void* d_frame, size_t frame_capacity_bytes, void* hip_stream) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;

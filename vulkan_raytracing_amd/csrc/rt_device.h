@@ -143,6 +143,14 @@ constexpr uint32_t ENTRY_REVERSE = 0x80000000u;      // per-ray flag: take the i
 struct alignas(16) EntryRec { int32_t w[2 + ENTRY_WORDS]; };
 static_assert(sizeof(EntryRec) == 32, "EntryRec must be 32 bytes");
 constexpr int ENTRY_VIEWS = 7;                       // camera + 6 light faces
+// Frame batches (rt_trace_shard_batch): up to BATCH_MAX consecutive frames go through ONE pass of the pipeline — a rank of an N-GPU split
+// renders its bands of K frames with the launches of one frame (a 1/8 shard of one frame is eight launches at their latency floors).  The
+// frames lie back to back in every buffer (frame k's samples at k * spp * rows * W, its image at k * rows * W), their instance records
+// are concatenated (instance ids are global: frame k's TLAS names k * n .. k * n + n - 1) and their TLAS trees follow one another
+// `tlas_stride` nodes apart in ONE quantisation; a ray finds its frame from its sample id.  In a batch each frame is one "view" of
+// k_cover / k_entry.
+constexpr int BATCH_MAX = 8;
+constexpr int MAX_VIEWS = 8;                         // >= ENTRY_VIEWS, >= BATCH_MAX
 constexpr int LIGHT_TILES_DEFAULT = 256;             // tiles per side of a light face (rt_set_param "light_tiles")
 // Tile blobs (k_blob / k_tile, round 4): "BVH nodes and triangle packets staged through LDS".  For every 8x8-pixel tile whose entry
 // record names an instance, k_blob continues the beam search of k_entry down to the leaves and writes what the tile's beam can touch of

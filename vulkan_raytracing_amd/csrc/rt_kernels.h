@@ -11,6 +11,8 @@ struct SceneDev {
   const BvhNodeQ* blas_nodes;  // variant 0: quantized BVH2 nodes of all meshes, then the quantized TLAS nodes
   int tlas_root;               // index of the TLAS root in blas_nodes
   int tlas_nodes;              // nodes of this slot's TLAS (they follow the root)
+  int tlas_stride;             // frame batches: frame k's TLAS root is tlas_root + k * tlas_stride (0: no batch)
+  uint32_t batch_samples;      // frame batches: sample ids per frame (spp * rows * W): frame of a ray = sample id / batch_samples (0: no batch)
   const float4* tris;          // 3 float4 per TriPacket
   float tlas_q_lo[3], tlas_q_scale[3];
   const WideNodeQ* wide_nodes; // variant 2: 4-ary records, same numbering as blas_nodes
@@ -69,6 +71,9 @@ struct FrameDev {
   int far_possible;            // LaunchCfg::far of this frame (k_raygen's TLAS test)
   // (ux, uy) of every sample of this frame size and shard layout (k_jitter_table; NULL: k_raygen evaluates the hash itself)
   const float2* jitter;
+  // frame batch (rt_device.h BATCH_MAX): `rows` stays the rows of ONE frame's shard; the buffers hold batch_k of them back to back
+  int batch_k;                 // 1: a single frame
+  uint32_t cover_view_words;   // words of ONE view's coverage mask (frame k's camera mask starts k * cover_view_words into `cover`)
   // Tile blobs (rt_device.h; NULL: off).  tile_blob[local tile] = arena slot of the tile's blob or BLOB_NONE (k_blob): k_raygen leaves
   // the tiles that have one to k_tile, which generates their rays itself, walks them in LDS, puts them (ray direction + hit record) at the
   // TOP of their shard's region of bounce queue 0 (Q_TILE_RAYS; k_shade reads both ends) and appends the few that may still hit
@@ -89,8 +94,9 @@ struct CoverArgs {
   int width, height, tiles_x, tiles_y;
   int n_inst;
   uint32_t mask_offset;        // words from the start of the frame's mask block to this view's mask (word 0: everything marked)
+  int inst_base;               // first instance record of this view (frame batches: the view is a frame, its instances follow the previous frame's)
 };
-struct CoverViews { CoverArgs v[ENTRY_VIEWS]; int n; };
+struct CoverViews { CoverArgs v[MAX_VIEWS]; int n; };
 
 // beam of a tile (k_entry): apex cam, directions ux * R + uy * U + kf * F with (a, b, c) = inv * (P - cam) the coordinates of a
 // point in the basis (R, U, F); the camera: R, U, F = right, up, forward, kf = 2.5 (src/shader.rgen:79)
@@ -107,8 +113,15 @@ struct EntryArgs {
   EntryRec* records;
   const uint32_t* cover;       // coverage mask of this view (tiles it leaves unmarked get an empty record)
   int cover_tiles_x;
+  int tlas_root_offset;        // frame batches: this view's (frame's) TLAS root is sc.tlas_root + tlas_root_offset
 };
-struct EntryViews { EntryArgs v[ENTRY_VIEWS]; int n; };
+struct EntryViews { EntryArgs v[MAX_VIEWS]; int n; };
+
+// per-frame camera and light of a batch (kernel argument of k_raygen / k_shade / k_tail; frame 0 = the uniform block proper)
+struct BatchTab {
+  float position[BATCH_MAX][4], right[BATCH_MAX][4], up[BATCH_MAX][4], forward[BATCH_MAX][4];
+  float light[BATCH_MAX][4];
+};
 
 struct LaunchCfg {
   int trace_blocks;            // persistent grid of the traversal kernels (256 threads each)
@@ -122,8 +135,8 @@ struct LaunchCfg {
   int packet_blocks;           // persistent grid of k_packet (no LDS, few registers: eight workgroups per CU fit)
 };
 
-size_t raygen_block_count(int width, int rows, uint32_t spp);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
-void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, hipStream_t s);
+size_t raygen_block_count(int width, int rows, uint32_t spp, int batch_k);   // workgroups of k_raygen (each appends <= 256 rays to one shard)
+void launch_raygen(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, hipStream_t s);
 // the (ux, uy) table k_raygen reads through FrameDev::jitter: jitter_table_elems float2 for (f.width, f.rows, spp) and f's shard layout
 size_t jitter_table_elems(int width, int rows, uint32_t spp);
 void launch_jitter_table(const FrameDev& f, uint32_t spp, float2* table, hipStream_t s);
@@ -136,8 +149,8 @@ void launch_blob(const SceneDev& sc, const EntryArgs& e, const FrameDev& f, bool
 // the tiles with a blob: their primary rays generated and walked in LDS, one launch per size class
 void launch_tile(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, bool counting, hipStream_t s);
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
-void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
-void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, int bounce, const LaunchCfg& cfg, hipStream_t s);
+void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
+void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int bounce, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
 // marks the tiles of `mask` (FrameDev::cover layout) that the frontier boxes of the instances project onto
