@@ -61,6 +61,10 @@ def parse_args(argv=None):
                     help="N > 1: 'ranks' = one process per GPU over torch.distributed/RCCL (started by this script when no launcher did); "
                          "'multi' = ONE process drives all N GPUs through librt_multi.so (include/rt_multi.h: RCCL called from C++, no per-step Python "
                          "on the data path besides two ctypes calls)")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="frames per pass of the pipeline (rt_trace_shard_batch: K consecutive frames, each with its own instances and uniforms, rendered with the "
+                         "launches of one; one gather per batch).  0 = automatic: 1 on a single GPU (the reference's frame-by-frame loop on 4 frame slots), up to 8 "
+                         "when the frame is sharded over N > 1 GPUs (a 1/N shard of ONE frame is eight launches at their latency floors)")
     ap.add_argument("--loopback", action="store_true", help="--host multi only: N LOGICAL devices on cuda:0, shards moved by device copies instead of RCCL (rehearsal on one GPU)")
     return ap.parse_args(argv)
 
@@ -194,11 +198,19 @@ class Rig:
                 c.set_param("trace_blocks_per_cu", args.blocks_per_cu)
         band = self.band = tiling.BAND_ROWS
         rows_max = self.rows_max = tiling.max_shard_rows(H, band, n)
-        self.shards = [torch.zeros((rows_max, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
+        # frames per pass (rt_trace_shard_batch); 1 = the frame-by-frame loop
+        # (sharded: 8 per pass in a long run — 7.5 x the whole frame on 1/8 shards, profiles/r04_shard_ceiling.txt — 4 when the timed region
+        # is too short to fill a pipeline of 8-frame passes)
+        K = self.K = args.batch if args.batch > 0 else (1 if n == 1 else (8 if args.steps >= 64 else 4))
+        if K > 1 and args.rehearse_on_one_gpu:
+            K = self.K = 1
+        self.last_k = [1] * P            # frames in the last pass of every slot (its statistics are sums over them)
+        self.batched_before = [False] * P
+        self.shards = [torch.zeros((rows_max, W, 4) if K == 1 else (K, rows_max, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
         # the gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183)
         root_rank = rank == 0 and collective
-        self.gathered = [torch.zeros((n, rows_max, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
-        self.full = [torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
+        self.gathered = [torch.zeros((n, rows_max, W, 3) if K == 1 else (n, K, rows_max, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
+        self.full = [torch.zeros((H, W, 3) if K == 1 else (K, H, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
         self.perm = None
         if root_rank:
             src = np.zeros(H, np.int64)
@@ -241,6 +253,57 @@ class Rig:
             else:
                 self.frames[j] = self.shards[j]
 
+    def step_batch(self, b, animate=False):
+        """b <= K consecutive frames in ONE pass of the pipeline on the next slot (rt_set_batch + rt_trace_shard_batch), one gather for
+        all of them.  Every frame has its own instances and uniforms (the animated leg advances the clock b times)."""
+        a, n, rank, W, H = self.args, self.n, self.rank, self.wl.width, self.wl.height
+        j = self.counter % self.P
+        self.counter += 1
+        c = self.ctxs[j]
+        insts, unis = [], []
+        for _ in range(b):
+            if animate:
+                self.time_param = np.float32(self.time_param + np.float32(ANIM_DT) * np.float32(0.1))
+                insts.append(np.array(self.wl.animate(self.time_param)))
+            else:
+                insts.append(np.array(self.wl.instances))
+            unis.append(self.wl.uniforms)
+        c.set_batch(np.stack(insts), np.concatenate(unis), update=self.batched_before[j])
+        self.batched_before[j] = True
+        self.last_k[j] = b
+        with torch.cuda.stream(self.streams[j]):
+            buf = self.shards[j]
+            c.trace_shard_batch(W, H, self.band, rank, n, buf.data_ptr(), buf.numel() * 4, self.streams[j].cuda_stream,
+                                frame_stride_bytes=self.rows_max * W * 16)
+            if self.collective:
+                rgb = buf[..., :3].contiguous()
+                dist.gather(rgb, list(self.gathered[j].unbind(0)) if rank == 0 else None, dst=0)
+                if rank == 0:   # (shard, frame, row) -> (frame, shard * rows_max + row) -> frame rows
+                    g = self.gathered[j].permute(1, 0, 2, 3, 4).reshape(self.K, n * self.rows_max, W, 3)
+                    torch.index_select(g, 1, self.perm, out=self.full[j])
+                    self.frames[j] = self.full[j][b - 1]
+            else:
+                self.frames[j] = buf[b - 1]
+
+    def run_frames(self, count, animate=False):
+        """`count` frames: one by one (K = 1) or in passes of up to K"""
+        if self.K == 1:
+            for _ in range(count):
+                self.step(animate)
+            return
+        while count > 0:
+            b = min(self.K, count)
+            self.step_batch(b, animate)
+            count -= b
+
+    def single_frames(self):
+        """back to one frame per pass on every slot (the measurements behind the timed regions use rt_trace_shard)"""
+        self.sync()
+        for c in self.ctxs:
+            c.set_instances(self.wl.instances)
+            c.set_uniforms(self.wl.uniforms)
+        self.batched_before = [False] * self.P
+
     def sync(self):
         for s_ in self.streams:
             s_.synchronize()
@@ -250,13 +313,11 @@ class Rig:
             torch.cuda.synchronize(self.dev)
 
     def timed(self, steps, warmup, animate=False):
-        for _ in range(warmup):
-            self.step(animate)
+        self.run_frames(warmup, animate)
         self.sync()
         self.ctxs[0].stats()       # drop the warm-up frames' event times
         t0 = time.perf_counter()
-        for _ in range(steps):
-            self.step(animate)
+        self.run_frames(steps, animate)
         self.sync()
         return time.perf_counter() - t0
 
@@ -394,7 +455,9 @@ def main(args):
     if args.gpus != n:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (start it as `python3 bench.py --gpus N`, which launches the ranks itself, "
                          "or under torch.distributed.run with --nproc-per-node equal to --gpus)" % (args.gpus, n))
-    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else 16)
+    # frame slots: 4 whole frames in flight; 1/N shards one by one want 16 (each is latency-bound), in passes of several frames 4 again
+    batched = args.batch > 1 or (args.batch == 0 and n > 1 and not args.rehearse_on_one_gpu)
+    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if (n <= 2 or batched) else 16)
 
     res = os.path.join(ROOT, "resources")
     if rank == 0:
@@ -411,15 +474,15 @@ def main(args):
     # kernels otherwise run back to back), so bracketing all seven would slow every P-th frame by 50 us.
     ctx.set_timing(2)
     # set-up, not a step: one frame per slot so that every slot has its ray queues allocated before the warm-up/timed steps
-    for _ in range(P):
-        rig.step()
+    rig.run_frames(P * rig.K)
     rig.sync()
     mark("set-up frames done")
     dt = rig.timed(args.steps, args.warmup, animate=args.animate)
     mark("timed region done")
     st = ctx.stats()        # counters of slot 0's last frame + MEAN closest-hit launch time over all its timed frames (every P-th step)
     # the other kernels' live times: a short continuation of the same loop (same frames in flight) with events around every kernel
-    if not args.animate:
+    k0 = rig.last_k[0]      # frames in slot 0's last pass: its counters are sums over them
+    if not args.animate and rig.K == 1:
         ctx.set_timing(1)
         for _ in range(max(3 * P, 12)):
             rig.step()
@@ -432,7 +495,7 @@ def main(args):
     if args.save_image and rank == 0 and rig.frames[(rig.counter - 1) % P] is not None:
         last_frame = rig.frames[(rig.counter - 1) % P][:H].clone()   # the last frame of THE timed region
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    rays = torch.tensor([st.rays_primary, st.rays_secondary, st.rays_shadow], dtype=torch.float64, device=dev)
+    rays = torch.tensor([st.rays_primary / k0, st.rays_secondary / k0, st.rays_shadow / k0], dtype=torch.float64, device=dev)
     if collective:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
@@ -451,7 +514,7 @@ def main(args):
             dist.all_reduce(ta, op=dist.ReduceOp.MAX)
         anim_ms = float(ta.item()) / args.steps * 1e3
         # the animated frames are different frames (the orbiting mesh moves through the view): their own ray count, from the last frame of every slot
-        anim_rays = torch.tensor([float(sum(c.stats().rays_total for c in rig.ctxs)) / P], dtype=torch.float64, device=dev)
+        anim_rays = torch.tensor([float(sum(c.stats().rays_total / rig.last_k[j] for j, c in enumerate(rig.ctxs))) / P], dtype=torch.float64, device=dev)
         if collective:
             dist.all_reduce(anim_rays, op=dist.ReduceOp.SUM)
         anim_rays = float(anim_rays.item())
@@ -461,6 +524,39 @@ def main(args):
             c.set_instances(wl.instances)
         rig.sync()
         ctx.set_timing(1)
+    rig.single_frames()
+
+    # ---- the same frames in passes of 8 (rt_trace_shard_batch), single GPU, informational: `value` stays the frame-by-frame loop ------
+    batched_info = None
+    if n == 1 and rig.K == 1 and not args.no_extras and not args.animate:
+        KB = 8
+        bufs = [torch.zeros((KB, rig.rows_max, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
+        out = {}
+        for leg in ("static", "animated"):
+            tp = np.float32(0.0)
+            first = [True] * P
+            for phase in range(2):           # the first round allocates and warms up
+                rig.sync()
+                t0 = time.perf_counter()
+                for i in range(8):
+                    j = i % P
+                    insts = []
+                    for _ in range(KB):
+                        if leg == "animated":
+                            tp = np.float32(tp + np.float32(ANIM_DT) * np.float32(0.1))
+                            insts.append(np.array(wl.animate(tp)))
+                        else:
+                            insts.append(np.array(wl.instances))
+                    rig.ctxs[j].set_batch(np.stack(insts), np.concatenate([wl.uniforms] * KB), update=not first[j]); first[j] = False
+                    rig.ctxs[j].trace_shard_batch(W, H, rig.band, rank, n, bufs[j].data_ptr(), bufs[j].numel() * 4, rig.streams[j].cuda_stream)
+                rig.sync()
+                out[leg] = (time.perf_counter() - t0) / (8 * KB) * 1e3
+        rig.single_frames()
+        del bufs
+        batched_info = {"frames_per_pass": KB, "ms_per_step": out["static"], "animated_ms_per_step": out["animated"], "steps": 8 * KB,
+                        "note": "rt_set_batch + rt_trace_shard_batch: 8 consecutive frames (own instances and uniforms each) per pass of the pipeline, 4 slots in flight; "
+                                "the frames are bit-identical to the frame-by-frame ones (tests); not `value`: a pass needs the inputs of 8 frames ahead of time, "
+                                "which a recorded animation has and an interactive camera has not"}
 
     result = None
     if rank == 0:
@@ -483,8 +579,11 @@ def main(args):
                   "config": {"workload": wl.describe() + (" [animated loop timed]" if args.animate else ""), "mesh": wl.mesh_label,
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
                              "ray_classes": "value counts every traceRayEXT-equivalent: primary + secondary (bounce) + shadow rays; 'secondary' in the metric string means both",
-                             "parallelism": "interleaved %d-row bands over %d GPU(s), one scene per GPU, one RCCL gather per frame, %d frame slots in flight per GPU" % (rig.band, n, P),
-                             "frames_in_flight": P, "device": ctx.device_info,
+                             "parallelism": "interleaved %d-row bands over %d GPU(s), one scene per GPU, one RCCL gather per %s, %d frame slots in flight per GPU" % (
+                                 rig.band, n, "frame" if rig.K == 1 else "pass of %d frames" % rig.K, P),
+                             "frames_in_flight": P, "frames_per_pass": rig.K, "in_passes_of_8": batched_info, "device": ctx.device_info,
+                             "frame_batches": None if rig.K == 1 else "rt_set_batch + rt_trace_shard_batch: %d consecutive frames (own instances, camera and light each) go through one pass "
+                                              "of the pipeline; a rank's 1/N shard of ONE frame is eight launches at their latency floors" % rig.K,
                              "animated_loop": "per step: animate (fixed dt 1/60 s) -> rt_set_instances(update=1) = TLAS refit -> rt_set_uniforms -> frame; src/main.cpp:2836-2861, 2901-2903",
                              "kept_between_frames": "what depends on the light, the instances and the trees only, as in the reference: BLAS, TLAS, and (rt_set_param shadow_entry 2, "
                                                     "the default) the shadow rays' entry records around the light, rebuilt when the light or an instance moves — the timed "

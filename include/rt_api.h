@@ -207,11 +207,11 @@ int rt_trace_shard(rt_ctx* ctx, int width, int height, int band_rows, int shard,
  * rt_set_batch replaces rt_set_instances + rt_set_uniforms for the K frames: instances = n_frames x n records (frame k's at
  * instances + k * n, each frame a createTLAS(update) of the same topology, src/main.cpp:2848-2861), uniforms = n_frames blocks — camera
  * and light may differ from frame to frame, maxBounceCount / samplesPerPixel / object types are the batch's.  update as in rt_set_instances.
- * rt_trace_shard_batch is rt_trace_shard for the batch: frame k's compact shard lands at d_out + k * rows * width pixels; statistics are
- * sums over the batch.  Results are those of the K frames rendered one by one, bit for bit (tested). */
+ * rt_trace_shard_batch is rt_trace_shard for the batch: frame k's compact shard lands frame_stride_bytes behind frame k - 1's (0: back to
+ * back, rows * width pixels apart); statistics are sums over the batch.  Results are those of the K frames rendered one by one, bit for bit (tested). */
 int rt_set_batch(rt_ctx* ctx, int n_frames, const rt_instance* instances, int n, const rt_uniforms* uniforms, int update);
 int rt_trace_shard_batch(rt_ctx* ctx, int width, int height, int band_rows, int shard, int n_shards,
-                         void* d_out, size_t out_capacity_bytes, void* hip_stream);
+                         void* d_out, size_t frame_stride_bytes, size_t out_capacity_bytes, void* hip_stream);
 /* Frames in flight from a plain C/C++ host: rt_trace_async enqueues the frame and its copy to a pinned host buffer owned
  * by the context and returns (vkQueueSubmit with a fence, src/main.cpp:2905-2967); rt_trace_wait blocks until that frame
  * is complete (vkWaitForFences, src/main.cpp:772-778) and hands out the pixels (W*H*4 floats, or W*H*4 bytes with

@@ -1382,14 +1382,17 @@ def test_frame_batches_equal_the_frames_rendered_one_by_one(ctx):
         K = len(frames)
         ctx.set_batch(np.stack([f[0] for f in frames]), np.concatenate([f[1] for f in frames]), update=update)
         buf = torch.zeros((K, rows, W, 4), dtype=torch.float32, device="cuda:0")
-        ctx.trace_shard_batch(W, H, band, shard, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+        rows_real = ctx.shard_rows(H, band, shard, n)
+        padded = (K + band + shard) % 2 == 1       # frame k's shard rows_max rows behind frame k - 1's (a padded buffer), or back to back
+        ctx.trace_shard_batch(W, H, band, shard, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream,
+                              frame_stride_bytes=rows * W * 16 if padded else 0)
         st = ctx.stats()
         out = buf.cpu().numpy()
-        rows_real = ctx.shard_rows(H, band, shard, n)
         imgs = []
-        for k in range(K):   # frame k's compact shard follows frame k - 1's (rows_real rows each)
+        for k in range(K):
             flat = out.reshape(-1, W, 4)
-            img = np.zeros((rows, W, 4), np.float32); img[:rows_real] = flat[k * rows_real:(k + 1) * rows_real]
+            first_row = k * (rows if padded else rows_real)
+            img = np.zeros((rows, W, 4), np.float32); img[:rows_real] = flat[first_row:first_row + rows_real]
             imgs.append(img)
         return imgs, np.array([st.rays_primary, st.rays_secondary, st.rays_shadow], np.int64)
 

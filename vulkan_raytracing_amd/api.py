@@ -67,7 +67,7 @@ def lib(variant=None):
         L.rt_trace_async.argtypes = [vp, C.c_int, C.c_int]
         L.rt_trace_wait.argtypes = [vp, C.POINTER(vp), C.POINTER(RtStats)]
         L.rt_trace_shard.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
-        L.rt_trace_shard_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
+        L.rt_trace_shard_batch.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.c_size_t, vp]
         L.rt_set_batch.argtypes = [vp, C.c_int, vp, C.c_int, vp, C.c_int]
         L.rt_assemble_shards.argtypes = [vp, vp, C.c_int, C.c_size_t, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, vp]
         L.rt_shard_rows.argtypes = [C.c_int] * 4
@@ -217,8 +217,8 @@ class RtContext:
         inst = inst.reshape(K, -1)
         self._chk(self.L.rt_set_batch(self.h, K, _p(inst), inst.shape[1], _p(u), int(update)), "rt_set_batch")
 
-    def trace_shard_batch(self, W, H, band_rows, shard, n_shards, d_out_ptr, capacity_bytes, stream_ptr=None):
-        self._chk(self.L.rt_trace_shard_batch(self.h, W, H, band_rows, shard, n_shards, C.c_void_p(d_out_ptr), capacity_bytes,
+    def trace_shard_batch(self, W, H, band_rows, shard, n_shards, d_out_ptr, capacity_bytes, stream_ptr=None, frame_stride_bytes=0):
+        self._chk(self.L.rt_trace_shard_batch(self.h, W, H, band_rows, shard, n_shards, C.c_void_p(d_out_ptr), frame_stride_bytes, capacity_bytes,
                                               C.c_void_p(stream_ptr) if stream_ptr else None), "rt_trace_shard_batch")
 
     def assemble_shards(self, d_gathered_ptr, n_shards, shard_stride_bytes, W, H, band_rows, d_frame_ptr, capacity_bytes, stream_ptr=None):

@@ -815,7 +815,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       for (uint32_t w = 0; w < blockDim.y; w++) { const float4 c = s_col[w][lane]; r += c.x; g += c.y; b += c.z; al += c.w; }
       const float nn = (float)spp;
       const uint32_t p = ly * (uint32_t)f.width + x;
-      store_pixel(f, fi * npx1 + p, make_float4(r / nn, g / nn, b / nn, al / nn));
+      store_pixel(f, fi * f.out_frame_stride + p, make_float4(r / nn, g / nn, b / nn, al / nn));
       st_stream(&f.sample_color[fi * spp * npx1 + p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
     }
     return;
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
         for (uint32_t w = 0; w < blockDim.y; w++) { const float4 c = s_col[w][lane]; r += c.x; g += c.y; b += c.z; al += c.w; }
         const float nn = (float)spp;
         const uint32_t p = ly * (uint32_t)f.width + x;     // = the sample id of sample 0 (in its frame)
-        store_pixel(f, fi * npx1 + p, make_float4(r / nn, g / nn, b / nn, al / nn));
+        store_pixel(f, fi * f.out_frame_stride + p, make_float4(r / nn, g / nn, b / nn, al / nn));
         st_stream(&f.sample_color[fi * spp * npx1 + p], make_float4(0.f, 0.f, 0.f, PIXEL_DONE));
       }
     } else if (missed) st_stream(&f.sample_color[sid], miss_col);
@@ -1679,7 +1679,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
       r += c.x; g += c.y; b += c.z; al += c.w;
     }
     const float nn = (float)u.samples_per_pixel;
-    store_pixel(f, p, make_float4(r / nn, g / nn, b / nn, al / nn));
+    store_pixel(f, fi * f.out_frame_stride + p1, make_float4(r / nn, g / nn, b / nn, al / nn));
   }
   // The next frame of this context finds its counters zeroed (no memset dispatch per frame): it uses the other block.
   if (f.counters_next)

@@ -145,6 +145,7 @@ struct rt_ctx {
   // instances of all of them (frame k's at k * inst_per_frame), batch_uni their uniform blocks, and the slot's TLAS region their trees,
   // tlas_stride[parity] nodes apart, in one quantisation
   int batch_k = 1;
+  uint32_t batch_out_stride = 0;   // pixels between the frames' shard images in the caller's buffer (0: compact), set per rt_trace_shard_batch call
   int inst_per_frame = 0;
   int tlas_stride[2] = {0, 0};
   std::vector<UniformsDev> batch_uni;
@@ -236,7 +237,7 @@ struct rt_ctx {
   // what the last enqueued frame was rendered from: a re-render after a k_tail fault must produce THAT frame, whatever
   // rt_set_uniforms / rt_set_instances did since (the instance records and TLAS nodes of `parity` are still the frame's own
   // as long as inst_gen[parity] has not moved: one later rt_set_instances writes the other parity)
-  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; int batch_k; BatchTab bt; } last_frame{};
+  struct LastFrame { int W, H, band_rows, shard, n_shards; float4* d_out; bool counting; SceneDev sc; UniformsDev uni; int parity; uint64_t inst_gen; int batch_k; BatchTab bt; uint32_t out_frame_stride; } last_frame{};
   uint64_t inst_gen[2] = {0, 0};  // bumped whenever the records of that parity are rewritten
   // shadow_entry 2: the records of the cube around the light depend on the light, the instances and the trees only — like the TLAS they are
   // kept while those stand still: built in a context's first frame and in the second consecutive frame with a new key, used from then on, dropped when the key moves
@@ -821,7 +822,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (K > 1) sc.batch_samples = (uint32_t)((size_t)u.samples_per_pixel * (size_t)rows * (size_t)W);
   const int n_inst1 = K > 1 ? sc.n_inst / K : sc.n_inst;   // instances of one frame
   const int frame_parity = again ? again->parity : c->parity;
-  if (!again) { c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting, sc, u, c->parity, c->inst_gen[c->parity], K, bt}; c->frame_rerendered = false; }
+  if (!again) { c->last_frame = {W, H, band_rows, shard, n_shards, d_out, c->counting, sc, u, c->parity, c->inst_gen[c->parity], K, bt, c->batch_out_stride ? c->batch_out_stride : (uint32_t)((size_t)rows * W)}; c->frame_rerendered = false; }
   if (u.samples_per_pixel == 0) return fail(c, RT_ERR_INVALID_ARGUMENT, "samplesPerPixel must be >= 1");
   if (u.max_bounce_count + 2 > (uint32_t)CNT_MAX_BOUNCES) return fail(c, RT_ERR_INVALID_ARGUMENT, "maxBounceCount too large (max 69)");
   const size_t tiles = (size_t)((W + 7) / 8) * (size_t)((rows + 7) / 8) * (size_t)K;
@@ -845,6 +846,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   f.shard_cap = (uint32_t)shard_cap; f.width = W; f.height = H; f.rows = rows;
   f.band_rows = band_rows; f.shard = shard; f.n_shards = n_shards;
   f.batch_k = K;
+  f.out_frame_stride = again ? again->out_frame_stride : (c->batch_out_stride ? c->batch_out_stride : (uint32_t)((size_t)rows * W));
   // Primary-ray coverage mask: on when the bands are whole 8x8 tiles, the camera basis is invertible and the scene has boxes.
   // The mask of this frame was cleared by the previous frame's k_resolve (or at allocation); this frame's clears the other.
   // Views: 0 = the camera; 1..6 = the faces of a cube around the light, when the shadow rays take entry lists (below).
@@ -1727,7 +1729,7 @@ int rt_trace_shard(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shar
 // Root-side step of a multi-GPU frame: n_shards compact shards (as rt_trace_shard writes them, each padded to
 // shard_stride_bytes) lie back to back in d_gathered after the gather; this writes the width x height frame to d_frame on
 // hip_stream (NULL = the context's stream).  Pixel format = the context's ("output_rgba8").  Asynchronous.
-int rt_trace_shard_batch(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t out_capacity_bytes, void* hip_stream) {
+int rt_trace_shard_batch(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shards, void* d_out, size_t frame_stride_bytes, size_t out_capacity_bytes, void* hip_stream) {
   if (!c) return RT_ERR_INVALID_ARGUMENT;
   if (W <= 0 || H <= 0 || band_rows <= 0 || n_shards <= 0 || shard < 0 || shard >= n_shards || !d_out)
     return fail(c, RT_ERR_INVALID_ARGUMENT, "bad rt_trace_shard_batch arguments");
@@ -1736,10 +1738,17 @@ int rt_trace_shard_batch(rt_ctx* c, int W, int H, int band_rows, int shard, int 
   HIP_TRY(c, hipSetDevice(c->device));
   int r = ready_to_trace(c, true); if (r) return r;
   const int rows = rt_shard_rows(H, band_rows, shard, n_shards);
-  if ((size_t)rows * W * (c->out_rgba8 ? 4 : 16) * (size_t)c->batch_k > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for the shards of this batch");
+  const size_t px_bytes = c->out_rgba8 ? 4 : 16, shard_bytes = (size_t)rows * W * px_bytes;
+  if (frame_stride_bytes == 0) frame_stride_bytes = shard_bytes;
+  if (frame_stride_bytes < shard_bytes || frame_stride_bytes % px_bytes != 0 || frame_stride_bytes / px_bytes > 0xFFFFFFFFull)
+    return fail(c, RT_ERR_INVALID_ARGUMENT, "frame_stride_bytes must be 0 (compact) or a whole number of pixels >= one shard");
+  if (frame_stride_bytes * (size_t)(c->batch_k - 1) + shard_bytes > out_capacity_bytes) return fail(c, RT_ERR_INVALID_ARGUMENT, "output buffer too small for the shards of this batch");
   hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
   if (c->frame_pending && c->frame_stream != s) { int q = collect_stats(c); if (q) return q; }
-  return enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
+  c->batch_out_stride = (uint32_t)(frame_stride_bytes / px_bytes);
+  r = enqueue_frame(c, W, H, band_rows, shard, n_shards, (float4*)d_out, s);
+  c->batch_out_stride = 0;
+  return r;
 }
 
 int rt_assemble_shards(rt_ctx* c, const void* d_gathered, int n_shards, size_t shard_stride_bytes, int W, int H, int band_rows,

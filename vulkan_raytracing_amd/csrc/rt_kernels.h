@@ -73,6 +73,7 @@ struct FrameDev {
   const float2* jitter;
   // frame batch (rt_device.h BATCH_MAX): `rows` stays the rows of ONE frame's shard; the buffers hold batch_k of them back to back
   int batch_k;                 // 1: a single frame
+  uint32_t out_frame_stride;   // pixels between the shard images of consecutive frames of a batch in `out` (>= rows * width)
   uint32_t cover_view_words;   // words of ONE view's coverage mask (frame k's camera mask starts k * cover_view_words into `cover`)
   // Tile blobs (rt_device.h; NULL: off).  tile_blob[local tile] = arena slot of the tile's blob or BLOB_NONE (k_blob): k_raygen leaves
   // the tiles that have one to k_tile, which generates their rays itself, walks them in LDS, puts them (ray direction + hit record) at the
