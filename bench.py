@@ -22,6 +22,7 @@ Besides `value` (the contract: t = 0 frames, timed region of K steps) the line c
 import argparse
 import hashlib
 import json
+import re
 import os
 import sys
 import time
@@ -245,13 +246,26 @@ class Rig:
                 if rank == 0:
                     self.frames[j] = torch.cat(parts).index_select(0, self.perm.cpu()).to(self.dev)
             elif self.collective:
-                rgb = self.shards[j][..., :3].contiguous()
-                dist.gather(rgb, list(self.gathered[j].unbind(0)) if rank == 0 else None, dst=0)
-                if rank == 0:
-                    torch.index_select(self.gathered[j].view(n * self.rows_max, W, 3), 0, self.perm, out=self.full[j])
-                    self.frames[j] = self.full[j]
+                self._gather(j, 1)
             else:
                 self.frames[j] = self.shards[j]
+
+    def _gather(self, j, b):
+        """the ONE data-path collective of a frame (or of a pass of b frames): every rank's compact shard to rank 0, rows put back in
+        frame order there.  Enqueued on the current stream, behind the shard's kernels."""
+        n, rank, W = self.n, self.rank, self.wl.width
+        buf = self.shards[j]
+        rgb = buf[..., :3].contiguous()
+        dist.gather(rgb, list(self.gathered[j].unbind(0)) if rank == 0 else None, dst=0)
+        if rank != 0:
+            return
+        if self.K == 1:
+            torch.index_select(self.gathered[j].view(n * self.rows_max, W, 3), 0, self.perm, out=self.full[j])
+            self.frames[j] = self.full[j]
+        else:   # (shard, frame, row) -> (frame, shard * rows_max + row) -> frame rows
+            g = self.gathered[j].permute(1, 0, 2, 3, 4).reshape(self.K, n * self.rows_max, W, 3)
+            torch.index_select(g, 1, self.perm, out=self.full[j])
+            self.frames[j] = self.full[j][b - 1]
 
     def step_batch(self, b, animate=False):
         """b <= K consecutive frames in ONE pass of the pipeline on the next slot (rt_set_batch + rt_trace_shard_batch), one gather for
@@ -276,12 +290,7 @@ class Rig:
             c.trace_shard_batch(W, H, self.band, rank, n, buf.data_ptr(), buf.numel() * 4, self.streams[j].cuda_stream,
                                 frame_stride_bytes=self.rows_max * W * 16)
             if self.collective:
-                rgb = buf[..., :3].contiguous()
-                dist.gather(rgb, list(self.gathered[j].unbind(0)) if rank == 0 else None, dst=0)
-                if rank == 0:   # (shard, frame, row) -> (frame, shard * rows_max + row) -> frame rows
-                    g = self.gathered[j].permute(1, 0, 2, 3, 4).reshape(self.K, n * self.rows_max, W, 3)
-                    torch.index_select(g, 1, self.perm, out=self.full[j])
-                    self.frames[j] = self.full[j][b - 1]
+                self._gather(j, b)
             else:
                 self.frames[j] = buf[b - 1]
 
@@ -308,6 +317,19 @@ class Rig:
         for s_ in self.streams:
             s_.synchronize()
         torch.cuda.synchronize(self.dev)
+        # include/rt_api.h: a frame whose bounce kernel lost a grid barrier is rendered AGAIN by the call that collects it
+        # (rt_stats.frames_rerendered) — the gather enqueued behind the first attempt has then taken an incomplete shard.  Collect every
+        # slot; if ANY rank re-rendered a slot's frame, every rank repeats that slot's gather, so that the collective stays matched.
+        if self.collective and not self.args.rehearse_on_one_gpu:
+            again = torch.zeros(self.P, dtype=torch.int32, device=self.dev)
+            for j, c in enumerate(self.ctxs):
+                if c.stats().frames_rerendered:
+                    again[j] = 1
+            dist.all_reduce(again, op=dist.ReduceOp.MAX)
+            for j in [int(x) for x in torch.nonzero(again).flatten().tolist()]:
+                with torch.cuda.stream(self.streams[j]):
+                    self._gather(j, self.last_k[j])
+                self.streams[j].synchronize()
         if self.collective:
             dist.barrier()
             torch.cuda.synchronize(self.dev)
@@ -508,6 +530,7 @@ def main(args):
     anim_rays = 0.0
     if not args.no_extras and not args.animate:
         ctx.set_timing(False)
+        anim_clock0 = np.float32(rig.time_param)      # the clock the animated leg starts from (its warm-up frames included)
         dta = rig.timed(args.steps, max(P, args.warmup), animate=True)
         ta = torch.tensor([dta], dtype=torch.float64, device=dev)
         if collective:
@@ -532,13 +555,19 @@ def main(args):
         KB = 8
         bufs = [torch.zeros((KB, rig.rows_max, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
         out = {}
+        n_pass = max(P, (args.steps + KB - 1) // KB)
+        for c in rig.ctxs:
+            c.set_timing(False)          # (an event record between two kernels costs ~10 us of idle GPU)
         for leg in ("static", "animated"):
-            tp = np.float32(0.0)
             first = [True] * P
             for phase in range(2):           # the first round allocates and warms up
+                # the SAME frames as the frame-by-frame animated leg above: its clock, behind its warm-up frames
+                tp = np.float32(anim_clock0)
+                for _ in range(max(P, args.warmup)):
+                    tp = np.float32(tp + np.float32(ANIM_DT) * np.float32(0.1))
                 rig.sync()
                 t0 = time.perf_counter()
-                for i in range(8):
+                for i in range(n_pass):
                     j = i % P
                     insts = []
                     for _ in range(KB):
@@ -550,13 +579,15 @@ def main(args):
                     rig.ctxs[j].set_batch(np.stack(insts), np.concatenate([wl.uniforms] * KB), update=not first[j]); first[j] = False
                     rig.ctxs[j].trace_shard_batch(W, H, rig.band, rank, n, bufs[j].data_ptr(), bufs[j].numel() * 4, rig.streams[j].cuda_stream)
                 rig.sync()
-                out[leg] = (time.perf_counter() - t0) / (8 * KB) * 1e3
+                out[leg] = (time.perf_counter() - t0) / (n_pass * KB) * 1e3
         rig.single_frames()
+        ctx.set_timing(1)
         del bufs
-        batched_info = {"frames_per_pass": KB, "ms_per_step": out["static"], "animated_ms_per_step": out["animated"], "steps": 8 * KB,
+        batched_info = {"frames_per_pass": KB, "ms_per_step": out["static"], "animated_ms_per_step": out["animated"], "steps": n_pass * KB,
                         "note": "rt_set_batch + rt_trace_shard_batch: 8 consecutive frames (own instances and uniforms each) per pass of the pipeline, 4 slots in flight; "
                                 "the frames are bit-identical to the frame-by-frame ones (tests); not `value`: a pass needs the inputs of 8 frames ahead of time, "
-                                "which a recorded animation has and an interactive camera has not"}
+                                "which a recorded animation has and an interactive camera has not; the animated figure renders the frames of animated_ms_per_step's loop "
+                                "(same clock), rounded up to whole passes"}
 
     result = None
     if rank == 0:
@@ -647,6 +678,23 @@ def main(args):
                 "definition": "algorithmic bytes of ALL closest-hit and shadow traversal of one frame (same per-ray formula; shadow ray 48 B in, 16 B colour out) / ms_per_step: "
                               "what the %d overlapping frames deliver per unit of wall time, the figure comparable with north_star's '>= 60 %% of the HBM roofline in the "
                               "traversal kernel' in the configuration `value` is quoted on" % P}
+        # what really bounds the kernel (profiles/r03_l1_probe.txt): the rate at which a CU's vector-memory path serves divergent
+        # 16-byte lane requests — two per node visit, three per triangle test, whatever cache level they hit.  Achieved here against
+        # the probe's ceiling of 1.2 (set in L2) .. 1.6 (set in L1) requests per CU and cycle.
+        try:
+            n_cu = int(re.search(r"CUs=(\d+)", ctx.device_info).group(1))
+        except Exception:   # noqa: BLE001
+            n_cu = 256
+        clk_hz = torch.cuda.get_device_properties(dev).clock_rate * 1e3 if hasattr(torch.cuda.get_device_properties(dev), "clock_rate") else 2.4e9
+        req = closest_rays_rank0 * (2.0 * mean_nodes + 3.0 * mean_tris)
+        def _lim(ms):
+            per = req / launches / (ms * 1e-3 * clk_hz * n_cu) if ms > 0 else 0.0
+            return {"lane_requests_per_cu_cycle": per, "frac_of_probe_ceiling": [per / 1.6, per / 1.2]}
+        roof["limiter"] = {"name": "CU vector-memory path: divergent 16-byte lane requests (2 per node visit, 3 per triangle test), served from L1 / L2 / Infinity Cache",
+                           "lane_requests_per_launch": req / launches, "probe_ceiling_per_cu_cycle": [1.2, 1.6], "clock_hz": clk_hz, "cus": n_cu,
+                           "live": _lim(st.ms_trace_closest / launches), "isolated": _lim(iso_ms / launches),
+                           "source": "ceiling: tools/l1_probe.hip (profiles/r03_l1_probe.txt: dependent chains of random 32-byte nodes, 1.6 requests per CU cycle from "
+                                     "L1, 1.2 from L2, whatever the occupancy); requests: instrumented kernel's visit counts x rays of this launch"}
         # rocprofv3 figures are attached ONLY when the committed profile was taken on this very configuration and kernel source
         tag = {"workload": args.workload, "mesh": args.mesh, "variant": args.variant or 0, "n_gpus": n, "frames_in_flight": P, "kernels_sha16": kernels_sha16()}
         # one committed profile per workload: profiles/latest_profile.json is the headline's (cfg3), the others carry their name
@@ -663,7 +711,7 @@ def main(args):
                         roof["hbm_measured"] = {"bytes_per_launch": prof["hbm_bytes_per_launch"], "GB/s": prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9,
                                                 "frac_of_peak": prof["hbm_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "profile": prof.get("traffic_source")}
                     if prof.get("limiter"):
-                        roof["limiter"] = prof["limiter"]
+                        roof["limiter"]["profile"] = prof["limiter"]
                     if prof.get("k_trace_shadow_avg_ms"):
                         roof["shadow_rocprof"] = {"avg_launch_ms": prof["k_trace_shadow_avg_ms"], "hbm_bytes_per_launch": prof.get("hbm_bytes_per_launch_shadow")}
                 else:
@@ -674,6 +722,11 @@ def main(args):
         # from the all-kernels continuation of the timed loop
         sh_live_s = st_all.ms_trace_shadow * 1e-3
         sh_rate = sh_bytes / sh_live_s / 1e9 if sh_live_s > 0 else 0.0
+        if n == 1:   # both traversal kernels of a frame over wall time, as requests
+            req_frame = cst.node_visits * 2.0 + cst.tri_tests * 3.0 + cst.node_visits_shadow * 2.0 + cst.tri_tests_shadow * 3.0
+            per = req_frame / (result["ms_per_step"] * 1e-3 * clk_hz * n_cu)
+            roof["limiter"]["both_traversal_kernels_over_wall_time"] = {"lane_requests_per_frame": req_frame, "lane_requests_per_cu_cycle": per,
+                                                                        "frac_of_probe_ceiling": [per / 1.6, per / 1.2]}
         roof["shadow_kernel"] = {"bound": "hbm", "achieved": sh_rate, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sh_rate / HBM_PEAK_GBS,
                                  "kernel": "any-hit traversal k_trace<shadow> (flags 13, src/shader.rgen:66-67,111-112) + the rgen:114-129 epilogue",
                                  "avg_launch_ms": st_all.ms_trace_shadow, "algorithmic_bytes_per_launch": sh_bytes, "rays_per_frame_in_kernel": int(sh_rays),

@@ -470,7 +470,10 @@ def test_launcher_starts_ranks_relays_rank0_and_propagates_failures(tmp_path):
     rec = json.loads(lines[0])
     assert rec == {"rank": 0, "n_gpus": 3, "argv": ["--gpus", "3", "--steps", "5"]}
     t0 = time.time()
-    assert launcher.spawn_ranks(3, [sys.executable, str(fake), "fail1"], out=Sink(), err=Sink()) == 7
+    out2, err2 = Sink(), Sink()
+    assert launcher.spawn_ranks(3, [sys.executable, str(fake), "fail1"], out=out2, err=err2) == 7
+    # a failed job relays NO result line (rank 0 may have printed half of one) and names the failing rank on err
+    assert out2.getvalue() == "" and "rank 1 exited with status 7" in err2.getvalue()
     assert time.time() - t0 < 30, "the launcher waited for ranks it should have ended"
     assert launcher.spawn_ranks(2, [sys.executable, str(fake), "hang"], out=Sink(), err=Sink(), timeout_s=1.0) == 124
     e0, e1 = launcher.rank_env(0, 2, 1234, base={}), launcher.rank_env(1, 2, 1234, base={"HSA_ENABLE_IPC_MODE_LEGACY": "1"})

@@ -50,6 +50,15 @@ def main():
                                                                        float(r["AverageNs"]) / 1e3, r.get("Percentage", "")))
     tr = kernel_trace(os.path.join(base, "trace"))
     res["avg_us"] = {short(k): sum(v) / len(v) for k, v in tr.items()}
+    # the FULL-SIZE launches of the two traversal kernels: what profiles/latest_profile.json carries and bench.py's roofline.rocprof uses
+    # (a context's first frame also launches the same instantiations on its small later bounces; those are left out: < half the longest)
+    print("== full-size launches of the traversal kernels (the averages latest_profile.json carries) ==")
+    for k, v in sorted(tr.items(), key=lambda kv: -sum(kv[1])):
+        if "k_trace<" not in k and "k_tile<" not in k:
+            continue
+        durs = sorted(v)
+        big = [x for x in durs if x >= 0.5 * durs[-1]]
+        print("%-72s full-size launches %4d of %4d  avg %9.2f us  (all launches: avg %9.2f us)" % (short(k), len(big), len(durs), sum(big) / len(big), sum(durs) / len(durs)))
     for tag, ctr in (("pmc_fetch", "FETCH_SIZE"), ("pmc_write", "WRITE_SIZE"), ("pmc_l2", None)):
         p = pmc(os.path.join(base, tag))
         if not p:

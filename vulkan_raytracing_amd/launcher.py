@@ -54,6 +54,7 @@ def spawn_ranks(n, command, out=None, err=None, poll_s=0.05, timeout_s=None, bas
                                       stdout=subprocess.PIPE if r == 0 else (err_fd if err_fd is not None else subprocess.DEVNULL),
                                       stderr=err_fd, start_new_session=False))
     status = 0
+    failed = None        # (rank, status) of the first rank that failed
     t0 = time.monotonic()
     rank0_out = b""
     # rank 0's pipe is drained by communicate() at the end; its JSON line is far smaller than a pipe buffer, but a chatty
@@ -74,6 +75,7 @@ def spawn_ranks(n, command, out=None, err=None, poll_s=0.05, timeout_s=None, bas
             live.discard(r)
             if rc != 0 and status == 0:
                 status = 128 - rc if rc < 0 else rc
+                failed = (r, rc)
         if status != 0 or (timeout_s is not None and time.monotonic() - t0 > timeout_s):
             if status == 0:
                 status = 124
@@ -102,6 +104,13 @@ def spawn_ranks(n, command, out=None, err=None, poll_s=0.05, timeout_s=None, bas
         pass
     procs[0].stdout.close()
     text = rank0_out.decode(errors="replace")
+    if status != 0:
+        # a failed or timed-out job has no result: what rank 0 printed so far is NOT relayed as one (a consumer that parses stdout
+        # without looking at the exit status would take a partial line for the answer); the cause goes to `err` in one line
+        why = "timed out after %.0f s" % timeout_s if failed is None else "rank %d exited with status %d" % failed
+        err.write("[launcher] %d-rank job failed: %s (exit status %d); %d byte(s) of rank 0's stdout withheld\n" % (n, why, status, len(text)))
+        err.flush()
+        return status
     if text:
         out.write(text)
         out.flush()
