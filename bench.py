@@ -362,7 +362,9 @@ def main_multi(args):
     n = args.gpus
     if not args.loopback and torch.cuda.device_count() < n:
         raise SystemExit("bench.py --host multi --gpus %d: only %d device(s) visible (use --loopback to rehearse on one GPU)" % (n, torch.cuda.device_count()))
-    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if n <= 2 else 16)
+    # frames per pass (rtm_set_batch: the devices render their bands of K consecutive frames with the launches of one, ONE gather per pass)
+    K = args.batch if args.batch > 0 else (1 if n == 1 else (8 if args.steps >= 64 else 4))
+    P = args.frames_in_flight if args.frames_in_flight > 0 else (4 if (n <= 2 or K > 1) else 16)
     if args.loopback:
         P = min(P, max(1, 16 // n))     # all logical devices share one GPU: at most 16 frame slots on it take k_tail's full grid
     res = os.path.join(ROOT, "resources")
@@ -379,24 +381,42 @@ def main_multi(args):
     m.set_param("host_copy", 1 if args.save_image else 0)
     time_param = np.float32(0.0)
 
+    batched_before = [False] * P
+    last_b = [1]
+
     def run(steps, animate):
+        """`steps` frames, one by one (K = 1) or in passes of up to K; returns (pixels, stats) of the LAST pass and leaves its size in last_b"""
         nonlocal time_param
-        pending = [False] * P
+        pending = [0] * P
         last = None
-        for i in range(steps):
+        order = []
+        done = i = 0
+        while done < steps:
             j = i % P
+            b = min(K, steps - done)
             if pending[j]:
-                last = m.trace_wait(j, copy=False)
-            if animate:
-                time_param = np.float32(time_param + np.float32(ANIM_DT) * np.float32(0.1))
-                m.set_instances(wl.animate(time_param), update=True, slot=j)
-                m.set_uniforms(wl.uniforms, slot=j)
+                last = m.trace_wait(j, copy=False); last_b[0] = pending[j]; order.remove(j)
+            if K == 1:
+                if animate:
+                    time_param = np.float32(time_param + np.float32(ANIM_DT) * np.float32(0.1))
+                    m.set_instances(wl.animate(time_param), update=True, slot=j)
+                    m.set_uniforms(wl.uniforms, slot=j)
+            else:
+                insts = []
+                for _ in range(b):
+                    if animate:
+                        time_param = np.float32(time_param + np.float32(ANIM_DT) * np.float32(0.1))
+                        insts.append(np.array(wl.animate(time_param)))
+                    else:
+                        insts.append(np.array(wl.instances))
+                m.set_batch(j, np.stack(insts), np.concatenate([wl.uniforms] * b), update=batched_before[j])
+                batched_before[j] = True
             m.trace_async(j, W, H)
-            pending[j] = True
-        for k in range(1, P + 1):
-            j = (steps - 1 + k) % P
-            if pending[j]:
-                last = m.trace_wait(j, copy=False)
+            pending[j] = b
+            order.append(j)
+            done += b; i += 1
+        for j in list(order):          # collect what is in flight, oldest first
+            last = m.trace_wait(j, copy=False); last_b[0] = pending[j]; pending[j] = 0
         return last
 
     run(P, False)                      # set-up: every slot allocates its queues
@@ -405,14 +425,17 @@ def main_multi(args):
     t0 = time.perf_counter()
     px, st = run(args.steps, args.animate)
     dt = time.perf_counter() - t0      # every frame collected: rtm_trace_wait waits for the devices and for the root's gather + de-interleave
+    kb = last_b[0]                     # frames in the last pass: its statistics are sums over them, its pixels kb frames back to back
     anim_ms = anim_rays = None
     if not args.no_extras and not args.animate:
         run(max(P, args.warmup), True)
         t0 = time.perf_counter()
         _, sta = run(args.steps, True)
         anim_ms = (time.perf_counter() - t0) / args.steps * 1e3
-        anim_rays = sta.rays_total
+        anim_rays = sta.rays_total / last_b[0]
         m.set_instances(wl.instances)
+        for j in range(P):
+            batched_before[j] = False
     ms_step = dt / args.steps * 1e3
     mb = int(wl.uniforms[0]["max_bounce_count"])
     metric = "Mrays/sec (primary+secondary+shadow) at %dx%d depth %d" % (W, H, mb + 1)
@@ -421,19 +444,20 @@ def main_multi(args):
             metric = json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
         except Exception:
             pass
-    result = {"metric": metric, "value": st.rays_total * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+    result = {"metric": metric, "value": st.rays_total / kb * args.steps / dt / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
               "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
               "animated_ms_per_step": anim_ms, "animated_value": (anim_rays / anim_ms / 1e3) if anim_ms else None,
               "config": {"workload": wl.describe() + (" [animated loop timed]" if args.animate else ""), "mesh": wl.mesh_label,
-                         "rays_per_frame": {"primary": st.rays_primary, "secondary": st.rays_secondary, "shadow": st.rays_shadow},
-                         "parallelism": "ONE host process, librt_multi.so: interleaved %d-row bands over %d %s, one scene per device, one %s per frame, "
+                         "rays_per_frame": {"primary": st.rays_primary // kb, "secondary": st.rays_secondary // kb, "shadow": st.rays_shadow // kb},
+                         "parallelism": "ONE host process, librt_multi.so: interleaved %d-row bands over %d %s, one scene per device, one %s per %s, "
                                         "%d frame slots in flight per device" % (tiling.BAND_ROWS, n, "logical devices on one GPU (loopback)" if args.loopback else "GPUs",
-                                                                                 "device-to-device copy" if args.loopback else "RCCL gather (ncclGather in one group)", P),
-                         "frames_in_flight": P, "host": "multi"},
+                                                                                 "device-to-device copy" if args.loopback else "RCCL gather (ncclGather in one group)",
+                                                                                 "frame" if K == 1 else "pass of %d frames" % K, P),
+                         "frames_in_flight": P, "frames_per_pass": K, "host": "multi"},
               "roofline": None, "cpu_baseline": None,
               "note": "roofline / cpu_baseline are reported by the N = 1 run (python3 bench.py); this line is the N-GPU throughput of the one-process host"}
     if args.save_image and px is not None:
-        img = np.array(px, dtype=np.float32)
+        img = np.array(px if K == 1 else px[kb - 1], dtype=np.float32)
         with open(args.save_image, "wb") as fh:
             fh.write(b"PF4\n%d %d\n-1.0\n" % (W, H))
             fh.write(img[::-1].astype("<f4").tobytes())

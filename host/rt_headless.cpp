@@ -9,6 +9,8 @@
 //               [--skybox DIR] [--out PREFIX] [--device D] [--frames-in-flight P] [--rgba8 | --bgra8]
 //               [--gpus N [--loopback]]   N GPUs of this node in one process: band sharding + RCCL gather (include/rt_multi.h);
 //                                         --loopback = N logical devices on GPU D, shards moved by device copies (no RCCL)
+//               [--batch K]               with --gpus: K <= 8 consecutive frames per pass of the pipeline (rtm_set_batch), one gather per pass
+#include <algorithm>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -54,6 +56,7 @@ int main(int argc, char** argv) {
   int W = 800, H = 600;  // the reference's window size (src/main.cpp:805)
   int frames = 3, device = 0, inFlight = 1, gpus = 0, blocksPerCu = 0;
   bool rgba8 = false, bgra8 = false, loopback = false;
+  int batchK = 1;
   float dt = 1.0f / 60.0f;
   std::string center = CENTER_MESH_OBJ_PATH, orbiting = ORBITING_MESH_OBJ_PATH, skyDir = SKYBOX_TEXTURE_DIR, out = "frame";
   rt_uniforms uniformStructure = rthost::defaultUniforms();
@@ -76,6 +79,7 @@ int main(int argc, char** argv) {
     else if (a == "--gpus") gpus = atoi(next());
     else if (a == "--blocks-per-cu") blocksPerCu = atoi(next());   // persistent traversal grid (experiments; 0 = the library's choice)
     else if (a == "--loopback") loopback = true;
+    else if (a == "--batch") batchK = std::max(1, std::min(8, atoi(next())));   // --gpus N: frames per pass (rtm_set_batch: K consecutive frames, own instances each, one gather per pass)
     else if (a == "--bgra8") { rgba8 = true; bgra8 = true; }   // ... in the byte order of a B8G8R8A8 surface (surfaceFormatList[0], src/main.cpp:1204): <out>.bgra holds the raw bytes
     else if (a == "--rgba8") rgba8 = true;   // frames come back in the 8-bit surface format the reference presents (src/main.cpp:1899); needs --frames-in-flight > 1
     else if (a == "--frames-in-flight") inFlight = std::max(1, atoi(next()));   // the reference: swapchain image count, src/main.cpp:1203
@@ -129,35 +133,50 @@ int main(int argc, char** argv) {
         return inst;
       };
       for (int k = 0; k < inFlight; k++) { auto in = instances(); check(rtm_set_instances(multi, k, in.data(), 2, 0), "rtm_set_instances", multi); }
-      std::vector<char> pending(inFlight, 0);
-      uint64_t rays = 0; int collected = 0;
+      std::vector<int> pending(inFlight, 0);     // frames of the pass in flight on that slot
+      uint64_t rays = 0; int collected = 0, lastPass = 1;
       const void* px = nullptr;
       float timeParam = 0.f;
       auto collect = [&](int k) {
         rt_stats st{};
         check(rtm_trace_wait(multi, k, &px, &st), "rtm_trace_wait", multi);
-        rays += st.rays_primary + st.rays_secondary + st.rays_shadow; collected++; pending[k] = 0;
+        rays += st.rays_primary + st.rays_secondary + st.rays_shadow; collected += pending[k]; lastPass = pending[k]; pending[k] = 0;
       };
-      const int warm = std::min(frames, inFlight);
+      // a pass = batchK consecutive frames (--batch; 1 = frame by frame): every frame animates and refits on its own, the devices render
+      // their bands of all of them with the launches of one frame, ONE gather brings them to the root
+      const int warm = std::min(frames, inFlight);      // (frames, not passes: the sequence of frames does not depend on --batch)
       std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-      for (int frame = 0; frame < frames + warm; frame++) {
-        const int k = frame % inFlight;
-        if (pending[k]) collect(k);
-        if (frame == warm) {
-          for (int j = 0; j < inFlight; j++) if (pending[j]) collect(j);
-          rays = 0; collected = 0; t0 = std::chrono::steady_clock::now();
+      bool timed = false;
+      std::vector<int> order;
+      for (int frame = 0, pass = 0; frame < frames + warm; pass++) {
+        const int k = pass % inFlight;
+        if (pending[k]) { collect(k); order.erase(std::find(order.begin(), order.end(), k)); }
+        if (!timed && frame >= warm) {
+          for (int j : order) collect(j);
+          order.clear();
+          rays = 0; collected = 0; t0 = std::chrono::steady_clock::now(); timed = true;
         }
-        timeParam += dt * 0.1f;
-        animation.animate(timeParam);
-        auto in = instances();
-        check(rtm_set_instances(multi, k, in.data(), 2, 1), "rtm_set_instances", multi);   // createTLAS(update = true), src/main.cpp:2853-2861
-        check(rtm_set_uniforms(multi, k, &uniformStructure), "rtm_set_uniforms", multi);    // copyData(uniform), src/main.cpp:2901-2903
+        const int b = std::min(batchK, (timed ? frames + warm : warm) - frame);
+        if (batchK == 1) {
+          timeParam += dt * 0.1f;
+          animation.animate(timeParam);
+          auto in = instances();
+          check(rtm_set_instances(multi, k, in.data(), 2, 1), "rtm_set_instances", multi);   // createTLAS(update = true), src/main.cpp:2853-2861
+          check(rtm_set_uniforms(multi, k, &uniformStructure), "rtm_set_uniforms", multi);    // copyData(uniform), src/main.cpp:2901-2903
+        } else {
+          std::vector<rt_instance> all;
+          std::vector<rt_uniforms> us((size_t)b, uniformStructure);
+          for (int j = 0; j < b; j++) { timeParam += dt * 0.1f; animation.animate(timeParam); auto in = instances(); all.insert(all.end(), in.begin(), in.end()); }
+          check(rtm_set_batch(multi, k, b, all.data(), 2, us.data(), 1), "rtm_set_batch", multi);
+        }
         check(rtm_trace_async(multi, k, W, H), "rtm_trace_async", multi);
-        pending[k] = 1;
+        pending[k] = b; order.push_back(k);
+        frame += b;
       }
-      const int last = (frames + warm - 1) % inFlight;
-      for (int j = 1; j <= inFlight; j++) { const int k = (last + j) % inFlight; if (pending[k]) collect(k); }
+      for (int j : order) collect(j);
+      px = static_cast<const char*>(px) + (size_t)(lastPass - 1) * (size_t)W * H * (rgba8 ? 4 : 16);   // the last frame of the last pass
       const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (batchK > 1) printf("passes of %d frames (rtm_set_batch)\n", batchK);
       printf("%d frames on %d %s, %d in flight: %dx%d  %.3f ms per frame  %.1f Mrays/s with every frame gathered on device %d and copied to host memory  mesh: %s\n",
              collected, gpus, loopback ? "logical devices (loopback, one GPU)" : "GPUs (RCCL gather)", inFlight, W, H, ms / collected, rays / (ms * 1e3), ids[0], meshLabel.c_str());
       if (rgba8) {

@@ -46,8 +46,10 @@ struct rtm_ctx {
   // root side, per slot
   std::vector<void*> gathered, frame;
   std::vector<void*> h_frame;
-  std::vector<int> pending_w, pending_h;
+  std::vector<int> pending_w, pending_h, pending_k;
+  std::vector<int> batch_k;                   // frames per pass of every slot (rtm_set_batch; 1 after rtm_set_instances)
   size_t stride = 0, frame_bytes = 0;         // current allocation (bytes per shard, bytes per frame)
+  int alloc_k = 1;                            // frames per pass the buffers hold
   std::string error;
 };
 
@@ -85,16 +87,19 @@ int max_shard_rows(int H, int n) {
   return m;
 }
 
-int ensure_buffers(rtm_ctx* c, int W, int H) {
+// K: frames per pass (frame batches): every buffer holds K frames' worth — a device's K compact shards `stride` apart, the root's
+// gathered block [device][frame], K assembled frames back to back
+int ensure_buffers(rtm_ctx* c, int W, int H, int K) {
   const size_t bpp = c->rgba8 ? 4 : 16;
   const int n = (int)c->dev.size();
-  const size_t stride = (size_t)max_shard_rows(H, n) * W * bpp, frame_bytes = (size_t)W * H * bpp;
-  if (stride <= c->stride && frame_bytes <= c->frame_bytes) return RT_OK;
+  size_t stride = (size_t)max_shard_rows(H, n) * W * bpp, frame_bytes = (size_t)W * H * bpp;
+  if (stride <= c->stride && frame_bytes <= c->frame_bytes && K <= c->alloc_k) return RT_OK;
+  stride = std::max(stride, c->stride); frame_bytes = std::max(frame_bytes, c->frame_bytes); K = std::max(K, c->alloc_k);
   // growing: nothing may be in flight on the old buffers
   for (auto& d : c->dev) { HIPM(c, hipSetDevice(d.id)); for (auto s : d.streams) HIPM(c, hipStreamSynchronize(s)); }
   for (auto& d : c->dev) {
     HIPM(c, hipSetDevice(d.id));
-    for (auto& p : d.shard) { if (p) HIPM(c, hipFree(p)); p = nullptr; HIPM(c, hipMalloc(&p, stride)); }
+    for (auto& p : d.shard) { if (p) HIPM(c, hipFree(p)); p = nullptr; HIPM(c, hipMalloc(&p, stride * K)); }
   }
   HIPM(c, hipSetDevice(c->dev[0].id));
   for (int j = 0; j < c->P; j++) {
@@ -102,19 +107,20 @@ int ensure_buffers(rtm_ctx* c, int W, int H) {
     if (c->frame[j]) HIPM(c, hipFree(c->frame[j]));
     if (c->h_frame[j]) HIPM(c, hipHostFree(c->h_frame[j]));
     c->gathered[j] = c->frame[j] = c->h_frame[j] = nullptr;
-    HIPM(c, hipMalloc(&c->gathered[j], stride * n));
-    HIPM(c, hipMalloc(&c->frame[j], frame_bytes));
-    HIPM(c, hipHostMalloc(&c->h_frame[j], frame_bytes, hipHostMallocDefault));
+    HIPM(c, hipMalloc(&c->gathered[j], stride * n * K));
+    HIPM(c, hipMalloc(&c->frame[j], frame_bytes * K));
+    HIPM(c, hipHostMalloc(&c->h_frame[j], frame_bytes * K, hipHostMallocDefault));
   }
-  c->stride = stride; c->frame_bytes = frame_bytes;
+  c->stride = stride; c->frame_bytes = frame_bytes; c->alloc_k = K;
   return RT_OK;
 }
 
 // steps 2 and 3 of a frame, enqueued behind the devices' bands: ONE gather of the compact shards to the root, the de-interleave
 // and (host_copy) the copy to pinned host memory
-int gather_and_assemble(rtm_ctx* c, int slot, int W, int H) {
+int gather_and_assemble(rtm_ctx* c, int slot, int W, int H, int K) {
   const int n = (int)c->dev.size();
   const size_t bpp = c->rgba8 ? 4 : 16, frame_bytes = (size_t)W * H * bpp;
+  const size_t part = c->stride * (size_t)K;     // what one device contributes: its K shards
   hipStream_t root_stream = c->dev[0].streams[slot];
   if (c->flags & RTM_LOOPBACK) {
     for (int d = 0; d < n; d++) {
@@ -125,7 +131,7 @@ int gather_and_assemble(rtm_ctx* c, int slot, int W, int H) {
     HIPM(c, hipSetDevice(c->dev[0].id));
     for (int d = 0; d < n; d++) {
       if (d != 0) HIPM(c, hipStreamWaitEvent(root_stream, c->dev[d].done[slot], 0));
-      HIPM(c, hipMemcpyAsync((char*)c->gathered[slot] + (size_t)d * c->stride, c->dev[d].shard[slot], c->stride, hipMemcpyDeviceToDevice, root_stream));
+      HIPM(c, hipMemcpyAsync((char*)c->gathered[slot] + (size_t)d * part, c->dev[d].shard[slot], part, hipMemcpyDeviceToDevice, root_stream));
     }
   } else {
     std::vector<ncclComm_t>& set = c->comm[(size_t)slot % c->comm.size()];
@@ -133,14 +139,17 @@ int gather_and_assemble(rtm_ctx* c, int slot, int W, int H) {
     for (int d = 0; d < n; d++) {
       Device& D = c->dev[d];
       HIPM(c, hipSetDevice(D.id));
-      NCCLM(c, ncclGather(D.shard[slot], d == 0 ? c->gathered[slot] : nullptr, c->stride, ncclUint8, 0, set[d], D.streams[slot]));
+      NCCLM(c, ncclGather(D.shard[slot], d == 0 ? c->gathered[slot] : nullptr, part, ncclUint8, 0, set[d], D.streams[slot]));
     }
     NCCLM(c, ncclGroupEnd());
   }
   // the root de-interleaves and hands the frame to the host
   HIPM(c, hipSetDevice(c->dev[0].id));
-  RTM(c, 0, slot, rt_assemble_shards(c->dev[0].slots[slot], c->gathered[slot], n, c->stride, W, H, BAND_ROWS, c->frame[slot], c->frame_bytes, root_stream));
-  if (c->host_copy) HIPM(c, hipMemcpyAsync(c->h_frame[slot], c->frame[slot], frame_bytes, hipMemcpyDeviceToHost, root_stream));
+  // (frame k of a pass: its shards lie `part` apart in the gathered block, k * stride in; the assembled frames go back to back)
+  for (int k = 0; k < K; k++)
+    RTM(c, 0, slot, rt_assemble_shards(c->dev[0].slots[slot], (const char*)c->gathered[slot] + (size_t)k * c->stride, n, part, W, H, BAND_ROWS,
+                                       (char*)c->frame[slot] + (size_t)k * frame_bytes, c->frame_bytes, root_stream));
+  if (c->host_copy) HIPM(c, hipMemcpyAsync(c->h_frame[slot], c->frame[slot], frame_bytes * (size_t)K, hipMemcpyDeviceToHost, root_stream));
   return RT_OK;
 }
 
@@ -182,7 +191,7 @@ int rtm_create(rtm_ctx** out, int n_devices, const int* device_ids, int frames_i
     }
   }
   c->gathered.assign(c->P, nullptr); c->frame.assign(c->P, nullptr); c->h_frame.assign(c->P, nullptr);
-  c->pending_w.assign(c->P, 0); c->pending_h.assign(c->P, 0);
+  c->pending_w.assign(c->P, 0); c->pending_h.assign(c->P, 0); c->pending_k.assign(c->P, 1); c->batch_k.assign(c->P, 1);
   if (!(flags & RTM_LOOPBACK)) {
     // a few communicator sets shared by the frame slots: collectives of frames in flight rarely queue behind one another, and the
     // number of communicators does not grow with slots x devices (16 x 8 = 128 of them took seconds to create and pinned buffers each)
@@ -266,6 +275,13 @@ const void* rtm_frame_device(const rtm_ctx* c, int slot) { return (c && slot >= 
 int rtm_set_instances(rtm_ctx* c, int slot, const rt_instance* inst, int n, int update) {
   if (!c || slot < 0 || slot >= c->P) return RT_ERR_INVALID_ARGUMENT;
   for (size_t d = 0; d < c->dev.size(); d++) RTM(c, d, slot, rt_set_instances(c->dev[d].slots[slot], inst, n, update));
+  c->batch_k[slot] = 1;
+  return RT_OK;
+}
+int rtm_set_batch(rtm_ctx* c, int slot, int n_frames, const rt_instance* instances, int n, const rt_uniforms* uniforms, int update) {
+  if (!c || slot < 0 || slot >= c->P) return RT_ERR_INVALID_ARGUMENT;
+  for (size_t d = 0; d < c->dev.size(); d++) RTM(c, d, slot, rt_set_batch(c->dev[d].slots[slot], n_frames, instances, n, uniforms, update));
+  c->batch_k[slot] = n_frames;
   return RT_OK;
 }
 int rtm_set_uniforms(rtm_ctx* c, int slot, const rt_uniforms* u) {
@@ -277,15 +293,17 @@ int rtm_set_uniforms(rtm_ctx* c, int slot, const rt_uniforms* u) {
 int rtm_trace_async(rtm_ctx* c, int slot, int W, int H) {
   if (!c || slot < 0 || slot >= c->P || W <= 0 || H <= 0) return c ? fail(c, RT_ERR_INVALID_ARGUMENT, "bad rtm_trace_async arguments") : RT_ERR_INVALID_ARGUMENT;
   if (c->pending_w[slot]) return fail(c, RT_ERR_NOT_READY, "rtm_trace_async: the previous frame of this slot has not been collected (rtm_trace_wait)");
-  int r = ensure_buffers(c, W, H); if (r) return r;
+  const int K = c->batch_k[slot];
+  int r = ensure_buffers(c, W, H, K); if (r) return r;
   const int n = (int)c->dev.size();
-  // 1. every device renders its bands on the slot's stream
+  // 1. every device renders its bands on the slot's stream (of the K frames of the slot's pass: rtm_set_batch)
   for (int d = 0; d < n; d++) {
     Device& D = c->dev[d];
-    RTM(c, d, slot, rt_trace_shard(D.slots[slot], W, H, BAND_ROWS, d, n, D.shard[slot], c->stride, D.streams[slot]));
+    if (K == 1) RTM(c, d, slot, rt_trace_shard(D.slots[slot], W, H, BAND_ROWS, d, n, D.shard[slot], c->stride, D.streams[slot]));
+    else RTM(c, d, slot, rt_trace_shard_batch(D.slots[slot], W, H, BAND_ROWS, d, n, D.shard[slot], c->stride, c->stride * (size_t)K, D.streams[slot]));
   }
-  r = gather_and_assemble(c, slot, W, H); if (r) return r;
-  c->pending_w[slot] = W; c->pending_h[slot] = H;
+  r = gather_and_assemble(c, slot, W, H, K); if (r) return r;
+  c->pending_w[slot] = W; c->pending_h[slot] = H; c->pending_k[slot] = K;
   return RT_OK;
 }
 
@@ -307,7 +325,7 @@ int rtm_trace_wait(rtm_ctx* c, int slot, const void** pixels, rt_stats* stats) {
   if (again) {
     // a device rendered its bands a second time (k_tail fault, rt_api.h rt_trace_shard): the gather enqueued behind the first
     // attempt took the incomplete shard — gather, de-interleave and copy this slot's frame again
-    int r = gather_and_assemble(c, slot, W, H); if (r) return r;
+    int r = gather_and_assemble(c, slot, W, H, c->pending_k[slot]); if (r) return r;
     if (!(c->flags & RTM_LOOPBACK))
       for (auto& D : c->dev) { HIPM(c, hipSetDevice(D.id)); HIPM(c, hipStreamSynchronize(D.streams[slot])); }
   }

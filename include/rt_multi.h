@@ -56,6 +56,11 @@ int rtm_set_uniforms(rtm_ctx* ctx, int slot, const rt_uniforms* u);
 
 /* vkQueueSubmit of one frame (src/main.cpp:2933-2949): every device enqueues its bands, the gather and, on the root, the
  * de-interleave and the copy to a pinned host buffer; returns at once. */
+/* Frame batches (include/rt_api.h rt_set_batch): the slot's next rtm_trace_async renders n_frames CONSECUTIVE frames — each with its own
+ * instances (frame k's n records at instances + k * n), camera and light — in ONE pass on every device, with ONE gather for all of
+ * them; rtm_trace_wait then hands out n_frames frames back to back (width x height pixels each), rtm_frame_device likewise, and the
+ * statistics are sums over the pass.  rtm_set_instances puts the slot back to single frames. */
+int rtm_set_batch(rtm_ctx* ctx, int slot, int n_frames, const rt_instance* instances, int n, const rt_uniforms* uniforms, int update);
 int rtm_trace_async(rtm_ctx* ctx, int slot, int width, int height);
 /* vkWaitForFences for that frame: pixels = width*height RGBA32F (or RGBA8 after rtm_set_param "output_rgba8" 1), valid
  * until the next rtm_trace_async on the slot (NULL with "host_copy" 0); stats = ray counts summed over the devices, kernel

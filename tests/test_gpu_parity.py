@@ -934,14 +934,15 @@ def test_headless_multi_gpu_host_rccl_and_logical_shards(tmp_path):
     common = ["--width", "328", "--height", "203", "--frames", "5", "--dt", "0.5", "--bounce", "3", "--spp", "2", "--frames-in-flight", "2",
               "--center", os.path.join(RES, "teapot.obj"), "--orbiting", os.path.join(RES, "cube.obj"), "--skybox", os.path.join(RES, "skybox_texture_test")]
     outs = {}
-    for name, extra in (("single", []), ("loop4", ["--gpus", "4", "--loopback"]), ("rccl1", ["--gpus", "1"]), ("loop3", ["--gpus", "3", "--loopback"])):
+    for name, extra in (("single", []), ("loop4", ["--gpus", "4", "--loopback"]), ("rccl1", ["--gpus", "1"]), ("loop3", ["--gpus", "3", "--loopback"]),
+                        ("loop3_passes", ["--gpus", "3", "--loopback", "--batch", "3"]), ("rccl1_passes", ["--gpus", "1", "--batch", "4"])):
         out = str(tmp_path / name)
         r = subprocess.run([exe] + common + extra + ["--out", out], cwd=scenes.ROOT, capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, name + ": " + r.stdout[-800:] + r.stderr[-1500:]
         assert "Mrays/s" in r.stdout
         outs[name] = mod.read_image(out + ".pfm")
     assert outs["single"].shape == (203, 328, 3) and np.isfinite(outs["single"]).all() and outs["single"].std() > 0.01
-    for name in ("loop4", "rccl1", "loop3"):
+    for name in ("loop4", "rccl1", "loop3", "loop3_passes", "rccl1_passes"):     # (…_passes: rtm_set_batch, several frames per pass, one gather per pass)
         assert np.array_equal(outs[name], outs["single"]), name
     pp = {}
     for name, extra in (("single8", ["--rgba8"]), ("loop4_8", ["--gpus", "4", "--loopback", "--rgba8"])):
@@ -1899,7 +1900,18 @@ def test_bench_one_process_multi_gpu_host_reassembles_the_same_frame(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
     assert line["n_gpus"] == 2 and line["config"]["host"] == "multi" and line["value"] > 0
+    assert line["config"]["frames_per_pass"] == 4       # (round 4: the devices render passes of frames, one gather per pass)
     assert open(a, "rb").read() == open(b, "rb").read()
+    # the animated loop: every frame of a pass has its own instances (rtm_set_batch); 3 logical devices, passes of 3 frames
+    a2, b2 = str(tmp_path / "one_anim.pfm"), str(tmp_path / "multi_anim.pfm")
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-extras", "--animate", "--save-image", a2],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--gpus", "3", "--host", "multi", "--loopback", "--steps", "5", "--warmup", "2", "--batch", "3",
+                        "--no-extras", "--animate", "--save-image", b2], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert open(a2, "rb").read() == open(b2, "rb").read()
+    assert open(a2, "rb").read() != open(a, "rb").read()
 
 
 def test_far_origins_up_to_the_pipelines_tmax_and_beyond(ctx):

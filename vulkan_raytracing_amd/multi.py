@@ -12,7 +12,7 @@ from .api import INSTANCE_DTYPE, MATERIAL_DTYPE, MESH_RANGE_DTYPE, UNIFORMS_DTYP
 
 RTM_LOOPBACK = 1
 EXPORTS = ["rtm_create", "rtm_destroy", "rtm_upload_geometry", "rtm_build_blas", "rtm_set_skybox", "rtm_set_param", "rtm_set_materials",
-           "rtm_set_instance_types", "rtm_set_timing", "rtm_set_instances", "rtm_set_uniforms", "rtm_trace_async", "rtm_trace_wait",
+           "rtm_set_instance_types", "rtm_set_timing", "rtm_set_instances", "rtm_set_batch", "rtm_set_uniforms", "rtm_trace_async", "rtm_trace_wait",
            "rtm_frame_device", "rtm_device_count", "rtm_last_error"]
 _M = None
 
@@ -34,6 +34,7 @@ def mlib():
         L.rtm_set_instance_types.argtypes = [vp, C.c_int, vp, C.c_int]
         L.rtm_set_timing.argtypes = [vp, C.c_int]
         L.rtm_set_instances.argtypes = [vp, C.c_int, vp, C.c_int, C.c_int]
+        L.rtm_set_batch.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int]
         L.rtm_set_uniforms.argtypes = [vp, C.c_int, vp]
         L.rtm_trace_async.argtypes = [vp, C.c_int, C.c_int, C.c_int]
         L.rtm_trace_wait.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(RtStats)]
@@ -63,6 +64,7 @@ class RtMulti:
         self.h, self.P, self.n = h, frames_in_flight, len(device_ids)
         self._rgba8 = False
         self._shape = {}
+        self._k = {}
 
     def _chk(self, rc, fn):
         if rc:
@@ -95,6 +97,15 @@ class RtMulti:
         inst = np.ascontiguousarray(instances, INSTANCE_DTYPE)
         for j in (range(self.P) if slot is None else [slot]):
             self._chk(self.L.rtm_set_instances(self.h, j, _p(inst), len(inst), int(update)), "rtm_set_instances")
+            self._k[j] = 1
+
+    def set_batch(self, slot, instances, uniforms, update=False):
+        """rtm_set_batch: the slot's next trace_async renders K consecutive frames (instances (K, n), K uniform blocks) in one pass"""
+        u = np.ascontiguousarray(uniforms, UNIFORMS_DTYPE).reshape(-1)
+        K = len(u)
+        inst = np.ascontiguousarray(instances, INSTANCE_DTYPE).reshape(K, -1)
+        self._chk(self.L.rtm_set_batch(self.h, slot, K, _p(inst), inst.shape[1], _p(u), int(update)), "rtm_set_batch")
+        self._k[slot] = K
 
     def set_uniforms(self, uniforms, slot=None):
         u = np.ascontiguousarray(uniforms, UNIFORMS_DTYPE).reshape(1)
@@ -130,7 +141,8 @@ class RtMulti:
 
     def trace_async(self, slot, W, H):
         self._chk(self.L.rtm_trace_async(self.h, slot, W, H), "rtm_trace_async")
-        self._shape[slot] = (H, W, 4)
+        K = self._k.get(slot, 1)
+        self._shape[slot] = (H, W, 4) if K == 1 else (K, H, W, 4)
 
     def trace_wait(self, slot, copy=True):
         """(pixels or None with host_copy 0, stats)"""
