@@ -1424,6 +1424,22 @@ def test_frame_batches_equal_the_frames_rendered_one_by_one(ctx):
         ctx.set_batch(np.stack([f[0] for f in frames]), np.concatenate([f[1] for f in frames]))
         with pytest.raises(RtError):
             ctx.trace(W, H)                      # a context that holds a batch renders it with rt_trace_shard_batch
+        # a k_tail fault in a pass (forced on the host side): the WHOLE pass is rendered again from the state it was submitted with
+        c2 = RtContext(0)
+        try:
+            scenes.ScenePair(sp.geom_paths, sp.instances, sp.uniforms, sky=sp.sky, ctx=c2)
+            c2.set_param("tail_kernel", 2)
+            c2.set_batch(np.stack([f[0] for f in frames]), np.concatenate([f[1] for f in frames]))
+            buf = torch.zeros((4, H, W, 4), dtype=torch.float32, device="cuda:0")
+            c2.set_param("debug_force_tail_fault", 1)
+            c2.trace_shard_batch(W, H, 8, 0, 1, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+            st = c2.stats()
+            assert st.tail_faults == 1 and st.frames_rerendered == 1
+            got = buf.cpu().numpy()
+            for k in range(4):
+                assert np.array_equal(got[k], b_imgs[k][:H]), k
+        finally:
+            c2.close()
     finally:
         ctx.set_instances(sp.instances)
     # 17 instances per frame (more instance records than the kernels stage in LDS), glass centre: bounces through k_tail
