@@ -20,14 +20,14 @@ $(OBJDIR)/%.o: $(CSRC)/%.hip $(DEVHDRS)
 $(OBJDIR)/%.o: $(CSRC)/%.cpp $(DEVHDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -c -o $@ $<
-$(OBJDIR)/kernels.o: $(CSRC)/kernels_tile.inc
+$(OBJDIR)/kernels.o: $(CSRC)/kernels_tile.inc $(CSRC)/kernels_beam.inc
 PRODUCT_OBJS := $(OBJDIR)/kernels.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/rt_api.o $(OBJDIR)/bvh_build.o
 $(PKG)/librt_mi355x.so: $(PRODUCT_OBJS)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(PRODUCT_OBJS)
 
 # the traversal alternatives that measured slower (k_packet, the quad/BVH4 kernel, 4-ary records: csrc/kernels_alt.inc) are NOT in the
 # product library; `make alt` builds librt_mi355x_alt.so with them for the identity tests (RtContext(variant="alt") / RT_LIB_VARIANT=alt)
-$(OBJDIR)/kernels_alt.o: $(CSRC)/kernels.hip $(CSRC)/kernels_alt.inc $(CSRC)/kernels_tile.inc $(DEVHDRS)
+$(OBJDIR)/kernels_alt.o: $(CSRC)/kernels.hip $(CSRC)/kernels_alt.inc $(CSRC)/kernels_tile.inc $(CSRC)/kernels_beam.inc $(DEVHDRS)
 	@mkdir -p $(OBJDIR)
 	$(HIPCC) $(HIPFLAGS) -DRT_ALT_KERNELS -c -o $@ $(CSRC)/kernels.hip
 $(PKG)/librt_mi355x_alt.so: $(OBJDIR)/kernels_alt.o $(OBJDIR)/bvh_gpu.o $(OBJDIR)/rt_api.o $(OBJDIR)/bvh_build.o

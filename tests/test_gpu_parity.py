@@ -1542,6 +1542,77 @@ def test_tile_blobs_are_result_identical(ctx):
     assert o1[1][3].blob_tiles > 0 and o1[1][3].tile_rays_handed_on == 0
 
 
+def test_pixel_beams_are_result_identical(ctx):
+    """One walk per PIXEL for the primary rays (csrc/kernels_beam.inc, rt_set_param "pixel_beams", default on): the samples of a pixel
+    share the camera as origin, so one lane walks the tree once for all of them — boxes against the beam of the pixel's live rays
+    (conservative), triangles against every ray with the canonical test and tie rule.  Frames, ray counts and the rays that enter
+    traversal are identical with it on and off, the frame equals the oracle's, and the node visits show the path was taken.
+    Cameras: the start-up one, inside an instance's box, sheared, partly off screen and very close, far away, behind the camera, axis
+    aligned (directions that straddle an axis plane inside a pixel); band shards; overlapping instances; 17 instances; a one-instance
+    scene; sample counts 1, 3, 7 (a second, partly filled sample row group); a frame size that does not fill its last tiles."""
+    import torch
+    arm, _ = host.armadillo_path(RES)
+    sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+    W, H = 408, 232
+
+    def both(w=W, h=H):
+        out = {}
+        for on in (1, 0):
+            ctx.set_param("pixel_beams", on)
+            img, st = ctx.trace(w, h, counting=True)
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.closest_rays, st)
+        ctx.set_param("pixel_beams", 1)
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1] and out[1][2] == out[0][2], (out[1][1], out[0][1], out[1][2], out[0][2])
+        return out
+
+    base_u = sp.uniforms.copy()
+    try:
+        out = both()
+        # (the beams' node visits are counted per pixel: fewer than one walk per ray, even with two samples in pixels this coarse)
+        assert 0 < out[1][3].node_visits < 0.9 * out[0][3].node_visits, (out[1][3].node_visits, out[0][3].node_visits)
+        ref, rc = sp.orc.render(W, H)
+        check_image(out[1][0], ref)
+        assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        for band, n in ((8, 3), (16, 2)):
+            rows_max = tiling.max_shard_rows(H, band, n)
+            shards = []
+            for s in range(n):
+                buf = torch.zeros((rows_max, W, 4), dtype=torch.float32, device="cuda:0")
+                ctx.trace_shard(W, H, band, s, n, buf.data_ptr(), buf.numel() * 4, torch.cuda.current_stream().cuda_stream)
+                ctx.synchronize()
+                shards.append(buf.cpu().numpy())
+            assert np.array_equal(tiling.assemble(shards, H, W, band), out[1][0])
+        for pos, extra in (((0.3, 0.2, 5.2), {}), ((3.5, 0.5, 9.0), {}), ((0.0, 0.0, 2000.0), {}), ((6.0, 1.0, 14.0), {}), ((-4.0, 3.0, 12.0), {"center_object_type": 2, "max_bounce_count": 5}),
+                           ((0.0, 0.0, 20.0), {"forward": (0.0, 0.0, 1.0)}), ((0.0, 0.0, 20.0), {}), ((0.0, 0.0, 20.0), {"samples_per_pixel": 3}), ((1.0, 0.4, 16.0), {"samples_per_pixel": 7}),
+                           ((1.0, 0.4, 16.0), {"samples_per_pixel": 1})):
+            u = base_u.copy()
+            u[0]["position"][:3] = pos
+            for k, v in extra.items():
+                if k == "forward":
+                    u[0][k][:3] = v
+                else:
+                    u[0][k] = v
+            sp.set_uniforms(u)
+            both()
+            both(203, 117)
+        u = base_u.copy()
+        u[0]["right"][:3] = (1.3, 0.2, 0.1); u[0]["up"][:3] = (0.15, 0.8, -0.1); u[0]["forward"][:3] = (0.1, -0.05, -1.4)
+        sp.set_uniforms(u); o2 = both()
+        ref, rc = sp.orc.render(W, H)
+        check_image(o2[1][0], ref)
+    finally:
+        ctx.set_param("pixel_beams", 1)
+        sp.set_uniforms(base_u)
+    scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx)
+    both()
+    wl = workloads.make("cfg5", RES)
+    wl.apply(ctx, sky=scenes.synthetic_skybox(64))
+    both(480, 270)
+    wl1 = workloads.make("cfg1", RES)
+    wl1.apply(ctx)
+    both(256, 256)
+
+
 def test_jitter_table_is_bit_identical_to_evaluating_the_hash(ctx):
     """k_raygen reads (ux, uy) of every sample from a table computed once per (width, height, spp, shard layout)
     by the same device function (kernels.hip sample_uv / k_jitter_table) instead of evaluating two binary64 sines per sample and

@@ -836,10 +836,18 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
   if (threadIdx.x == 0 && threadIdx.y == 0) {
     uint32_t tot = 0;
     for (uint32_t w = 0; w < blockDim.y; w++) { const uint32_t c = s_run[w]; s_run[w] = tot; tot += c; }
+    if (f.pixel_runs && tot) {
+      // pixel runs (kernels_beam.inc): the tile's samples keep their places — 64 slots per sample row, traced or not
+      const uint32_t run = 64u * blockDim.y;
+      __hip_atomic_fetch_add(f.counters + cnt_tail(Q_DEAD, (int)shard), run - tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      tot = run;
+    }
     s_run[4] = tot ? atomicAdd(f.counters + cnt_tail(0, (int)shard), tot) : 0u;
+    s_run[0] = f.pixel_runs ? tot : s_run[0];   // (pixel runs: row 0's offset is not needed; the word says whether the tile has a run)
   }
   __syncthreads();
-  const uint32_t slot = s_run[4] + s_run[threadIdx.y] + prefix_rank(smask);
+  const bool run_tile = f.pixel_runs && s_run[0] != 0u;
+  const uint32_t slot = f.pixel_runs ? s_run[4] + 64u * threadIdx.y + lane : s_run[4] + s_run[threadIdx.y] + prefix_rank(smask);
   if (fuse) {   // (s_col / s_miss were written before the first barrier above)
     bool all = true;
     for (uint32_t w = 0; w < blockDim.y; w++) all = all && ((s_miss[w] >> lane) & 1ull) != 0ull;
@@ -854,12 +862,12 @@ __global__ __launch_bounds__(256) void k_raygen(SceneDev sc, FrameDev f, Uniform
       }
     } else if (missed) st_stream(&f.sample_color[sid], miss_col);
   }
-  if (survive) {
+  if (survive || run_tile) {
     const uint32_t v = shard * f.shard_cap + slot;
     // (with entry lists the ray carries its tile instead of tmax, which is the constant 10000 of src/shader.rgen:87)
     const F3 o = f.batch_k > 1 ? mk3(bt.position[fi][0], bt.position[fi][1], bt.position[fi][2]) : mk3(u.position[0], u.position[1], u.position[2]);
     st_stream(&f.ray_o[0][v], make_float4(o.x, o.y, o.z, f.entry != nullptr ? __uint_as_float(tile) : 10000.0f));
-    st_stream(&f.ray_d[0][v], make_float4(d.x, d.y, d.z, __uint_as_float(sid)));
+    st_stream(&f.ray_d[0][v], survive ? make_float4(d.x, d.y, d.z, __uint_as_float(sid)) : make_float4(0.f, 0.f, 0.f, __uint_as_float(SID_DEAD)));   // (a zero direction: no ray in this slot)
   }
 }
 
@@ -1418,6 +1426,7 @@ template <int MODE, bool ANY, bool WIDE, bool ENTRY = false, bool FAR = true, bo
 __global__ __launch_bounds__(256) void k_trace_count(TraceArgs a) { trace_body<MODE, ANY, true, WIDE, ENTRY, FAR, CONT>(a); }
 
 #include "kernels_tile.inc"   // k_blob, k_trace_tile: the tile's nodes and triangle packets staged through LDS
+#include "kernels_beam.inc"   // k_beam: the primary rays of a pixel walked together
 
 #ifdef RT_ALT_KERNELS
 #include "kernels_alt.inc"   // k_packet, k_trace4: alternatives measured slower, only in librt_mi355x_alt.so
@@ -1704,7 +1713,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
     auto cnt64 = [&](int word) { return (unsigned long long)ld_cursor(f.counters + word) | ((unsigned long long)ld_cursor(f.counters + word + 1) << 32); };
     if (t < (uint32_t)STAT_WORDS) {
       unsigned long long v = 0;
-      if (t == STAT_QUEUE0) { v = s_q[0] + s_q[Q_TILE_RAYS]; for (int k = 0; k < N_SHARDS; k++) v -= ld_cursor(f.counters + cnt_work(Q_TILE_RAYS, k)); }   // (a ray handed on counts once)
+      if (t == STAT_QUEUE0) { v = s_q[0] + s_q[Q_TILE_RAYS] - s_q[Q_DEAD]; for (int k = 0; k < N_SHARDS; k++) v -= ld_cursor(f.counters + cnt_work(Q_TILE_RAYS, k)); }   // (a ray handed on counts once)
       else if (t == STAT_TILE_RAYS) v = s_q[Q_TILE_RAYS];
       else if (t == STAT_CONT_RAYS) { for (int k = 0; k < N_SHARDS; k++) v += ld_cursor(f.counters + cnt_work(Q_TILE_RAYS, k)); }
       else if (t >= STAT_BLOB && t < STAT_BLOB + 5) v = ld_cursor(f.counters + CNT_BLOB_STATS + (int)(t - STAT_BLOB));
@@ -1830,6 +1839,11 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
     a.entry = f.entry;
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.trace_blocks), b(256);
+    if (f.pixel_runs) {   // one walk per pixel (kernels_beam.inc); f.pixel_runs = slots per run
+      if (counting) hipLaunchKernelGGL(k_beam_count, g, b, 0, s, a, (uint32_t)f.pixel_runs);
+      else hipLaunchKernelGGL(k_beam, g, b, 0, s, a, (uint32_t)f.pixel_runs);
+      return;
+    }
     if (f.tile_blob != nullptr) {   // queue 0 may hold rays k_tile handed on (tile blobs are off in frames with far rays)
       if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true, false, true>), g, b, 0, s, a);
       else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false, true>), g, b, 0, s, a);

@@ -207,6 +207,7 @@ struct rt_ctx {
   size_t entry_alloc_tiles = 0;
   // tile blobs (rt_device.h; kernels_tile.inc): 1 = k_blob writes, for every tile whose record names an instance, the nodes and triangle packets the tile's beam
   // can touch as one blob, and k_trace_tile walks the tile's primary rays through it in LDS (result-identical; needs entry_points)
+  int pixel_beams = 1;  // the primary rays of a pixel walked together (kernels_beam.inc): result-identical; rt_set_param("pixel_beams", 0) restores one walk per ray
   int tile_blobs = 0;   // OFF by default: result-identical and measured slower (profiles/r04_experiments.txt: a wave of k_tile spends two thirds of its life
                         // fetching its blob and storing its results, the walk itself is 2.6 x faster than the global one)
   uint32_t* d_tile_blob = nullptr;   // directory, one word per tile (allocated with d_entry)
@@ -892,6 +893,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   for (int k = 1; k < K && !far_frame; k++) far_frame = far_possible(c, c->batch_uni[k]);   // (against the instances of ALL frames: conservative)
   // ... and the tiles' blobs on the records (no far-ray logic in the LDS walk: such frames keep the global walk)
   const bool tile_on = entry_on && c->tile_blobs && !far_frame && K == 1;
+  // ... or one walk per PIXEL from the records (k_beam: no far-ray logic either; the alternatives' queues are per ray)
+  const bool beam_on = entry_on && c->pixel_beams && !tile_on && !far_frame && K == 1 && c->cfg.variant == 0 && c->cfg.packet == 0;
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
   // (kept records are paid once, so they also serve scenes of more instances than the per-frame camera records are worth building for)
   const bool light_on = K == 1 && cover_on && c->entry_points && c->cfg.variant == 0 && (entry_on || c->shadow_entry == 2) && c->shadow_entry &&
@@ -1007,6 +1010,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (c->stack_need > 120) cfg.packet = 0;   // deeper than k_packet's 128-entry wave stack (a degenerate LBVH): the one-lane kernels spill to HBM instead
   cfg.far = far_frame ? 1 : 0;
   f.far_possible = cfg.far;
+  f.pixel_runs = (beam_on && f.entry != nullptr) ? 64 * (int)std::min<uint32_t>(u.samples_per_pixel, 4u) : 0;
   if (c->jitter_table && rows > 0) { r = jitter_table_for(c, f, u.samples_per_pixel, s, &f.jitter); if (r) return r; }
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
@@ -1238,7 +1242,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1599,6 +1603,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "primary_cover") { c->primary_cover = value != 0; return RT_OK; }
   if (k == "jitter_table") { c->jitter_table = value != 0; return RT_OK; }
   if (k == "tile_blobs") { c->tile_blobs = value != 0; return RT_OK; }
+  if (k == "pixel_beams") { c->pixel_beams = value != 0; return RT_OK; }
 
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
   if (k == "packet_trace") {

@@ -83,6 +83,10 @@ struct FrameDev {
   char* blob_arena;
   uint32_t blob_slots;         // arena capacity (slots of BLOB_SLOT_BYTES): N_SHARDS sub-arenas of blob_slots / N_SHARDS
   uint4* blob_list;            // BLOB_CLASSES x N_SHARDS parts of blob_slots / N_SHARDS entries
+  // Pixel runs (kernels_beam.inc; 0: off): bounce queue 0 is NOT compacted — every covered tile with a traced sample owns a run of 64
+  // slots per sample row of its k_raygen workgroup (slot = run + 64 * row + pixel of the tile), so that k_beam finds the samples of a
+  // pixel together; a slot without a ray has a zero direction and gets HIT_DEAD as its hit record.
+  int pixel_runs;
 };
 
 // camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
