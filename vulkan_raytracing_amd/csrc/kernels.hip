@@ -1834,16 +1834,19 @@ void launch_trace_closest(const SceneDev& sc, const FrameDev& f, int bounce, boo
     return;
   }
 #endif
+  if (bounce == 0 && f.pixel_runs && cfg.variant == 0) {   // one walk per pixel (kernels_beam.inc); f.pixel_runs = slots per run
+    a.entry = f.entry;   // (NULL: the walks start at the TLAS root)
+    const dim3 g(cfg.trace_blocks), b(256);
+    if (counting) hipLaunchKernelGGL(k_beam_count, g, b, 0, s, a, (uint32_t)f.pixel_runs);
+    else hipLaunchKernelGGL(k_beam, g, b, 0, s, a, (uint32_t)f.pixel_runs);
+    return;
+  }
   if (bounce == 0 && f.entry != nullptr && cfg.variant == 0) {
     // primary rays start at their tile's entry record (k_entry)
     a.entry = f.entry;
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.trace_blocks), b(256);
-    if (f.pixel_runs) {   // one walk per pixel (kernels_beam.inc); f.pixel_runs = slots per run
-      if (counting) hipLaunchKernelGGL(k_beam_count, g, b, 0, s, a, (uint32_t)f.pixel_runs);
-      else hipLaunchKernelGGL(k_beam, g, b, 0, s, a, (uint32_t)f.pixel_runs);
-      return;
-    }
+
     if (f.tile_blob != nullptr) {   // queue 0 may hold rays k_tile handed on (tile blobs are off in frames with far rays)
       if (counting) hipLaunchKernelGGL((k_trace_count<MODE_CLOSEST, false, false, true, false, true>), g, b, 0, s, a);
       else hipLaunchKernelGGL((k_trace<MODE_CLOSEST, false, false, true, false, true>), g, b, 0, s, a);

@@ -894,7 +894,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // ... and the tiles' blobs on the records (no far-ray logic in the LDS walk: such frames keep the global walk)
   const bool tile_on = entry_on && c->tile_blobs && !far_frame && K == 1;
   // ... or one walk per PIXEL from the records (k_beam: no far-ray logic either; the alternatives' queues are per ray)
-  const bool beam_on = entry_on && c->pixel_beams && !tile_on && !far_frame && K == 1 && c->cfg.variant == 0 && c->cfg.packet == 0;
+  const bool beam_on = c->pixel_beams && !tile_on && !far_frame && c->cfg.variant == 0 && c->cfg.packet == 0;   // (without records the walks start at the TLAS root)
   // ... and for the shadow rays, which all end (within 0.01) at the light: a cube of light_tiles^2 tiles per face around it
   // (kept records are paid once, so they also serve scenes of more instances than the per-frame camera records are worth building for)
   const bool light_on = K == 1 && cover_on && c->entry_points && c->cfg.variant == 0 && (entry_on || c->shadow_entry == 2) && c->shadow_entry &&
@@ -1010,7 +1010,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (c->stack_need > 120) cfg.packet = 0;   // deeper than k_packet's 128-entry wave stack (a degenerate LBVH): the one-lane kernels spill to HBM instead
   cfg.far = far_frame ? 1 : 0;
   f.far_possible = cfg.far;
-  f.pixel_runs = (beam_on && f.entry != nullptr) ? 64 * (int)std::min<uint32_t>(u.samples_per_pixel, 4u) : 0;
+  f.pixel_runs = beam_on ? 64 * (int)std::min<uint32_t>(u.samples_per_pixel, 4u) : 0;
   if (c->jitter_table && rows > 0) { r = jitter_table_for(c, f, u.samples_per_pixel, s, &f.jitter); if (r) return r; }
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
