@@ -1547,6 +1547,9 @@ def test_pixel_beams_are_result_identical(ctx):
     share the camera as origin, so one lane walks the tree once for all of them — boxes against the beam of the pixel's live rays
     (conservative), triangles against every ray with the canonical test and tie rule.  Frames, ray counts and the rays that enter
     traversal are identical with it on and off, the frame equals the oracle's, and the node visits show the path was taken.
+    The same for the SHADOW rays of the primary hits (k_beam_shadow, "shadow_beams", default off — it measured slower): a beam seen from
+    the light, the rays' end points measured against a common one, a pixel's rays walked in groups of like direction; every frame of
+    this test is rendered three ways (both beams, neither, primary only).
     Cameras: the start-up one, inside an instance's box, sheared, partly off screen and very close, far away, behind the camera, axis
     aligned (directions that straddle an axis plane inside a pixel); band shards; overlapping instances; 17 instances; a one-instance
     scene; sample counts 1, 3, 7 (a second, partly filled sample row group); a frame size that does not fill its last tiles."""
@@ -1557,12 +1560,14 @@ def test_pixel_beams_are_result_identical(ctx):
 
     def both(w=W, h=H):
         out = {}
-        for on in (1, 0):
-            ctx.set_param("pixel_beams", on)
+        for on in (1, 0, 2):          # 2: pixel beams for the primary rays only, one walk per shadow ray
+            ctx.set_param("pixel_beams", 1 if on else 0)
+            ctx.set_param("shadow_beams", 1 if on == 1 else 0)
             img, st = ctx.trace(w, h, counting=True)
             out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.closest_rays, st)
-        ctx.set_param("pixel_beams", 1)
-        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1] and out[1][2] == out[0][2], (out[1][1], out[0][1], out[1][2], out[0][2])
+        ctx.set_param("pixel_beams", 1); ctx.set_param("shadow_beams", 0)
+        for k in (1, 2):
+            assert np.array_equal(out[k][0], out[0][0]) and out[k][1] == out[0][1] and out[k][2] == out[0][2], (k, out[k][1], out[0][1], out[k][2], out[0][2])
         return out
 
     base_u = sp.uniforms.copy()
@@ -1570,6 +1575,7 @@ def test_pixel_beams_are_result_identical(ctx):
         out = both()
         # (the beams' node visits are counted per pixel: fewer than one walk per ray, even with two samples in pixels this coarse)
         assert 0 < out[1][3].node_visits < 0.9 * out[0][3].node_visits, (out[1][3].node_visits, out[0][3].node_visits)
+        assert 0 < out[1][3].node_visits_shadow != out[2][3].node_visits_shadow, (out[1][3].node_visits_shadow, out[2][3].node_visits_shadow)   # (the shadow beams ran)
         ref, rc = sp.orc.render(W, H)
         check_image(out[1][0], ref)
         assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
@@ -1601,7 +1607,7 @@ def test_pixel_beams_are_result_identical(ctx):
         ref, rc = sp.orc.render(W, H)
         check_image(o2[1][0], ref)
     finally:
-        ctx.set_param("pixel_beams", 1)
+        ctx.set_param("pixel_beams", 1); ctx.set_param("shadow_beams", 0)
         sp.set_uniforms(base_u)
     scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 2, sky=scenes.synthetic_skybox(64), ctx=ctx)
     both()

@@ -15,12 +15,16 @@ ctx = RtContext(0)
 wl = workloads.make(name, RES, mesh=mesh)
 wl.apply(ctx)
 imgs = {}
-for on in (1, 0, 1, 0):
-    ctx.set_param("pixel_beams", on)
+for on in (1, 0, 2, 1, 0, 2):      # 2: pixel beams for the primary rays only
+    ctx.set_param("pixel_beams", 1 if on else 0)
+    ctx.set_param("shadow_beams", 1 if on == 1 else 0)
     img, st = ctx.trace(wl.width, wl.height, counting=True)
     imgs[on] = img
-    print("pixel_beams=%d counting: closest rays %d  node visits %d (%.2f per closest ray)  triangle tests %d (%.2f per closest ray)" % (
-        on, st.closest_rays, st.node_visits, st.node_visits / max(1, st.closest_rays), st.tri_tests, st.tri_tests / max(1, st.closest_rays)))
+    print("beams=%d counting: closest rays %d  node visits %d (%.2f per closest ray)  triangle tests %d (%.2f)  | shadow rays %d  node visits %.2f per ray  triangle tests %.2f" % (
+        on, st.closest_rays, st.node_visits, st.node_visits / max(1, st.closest_rays), st.tri_tests, st.tri_tests / max(1, st.closest_rays),
+        st.rays_shadow, st.node_visits_shadow / max(1, st.rays_shadow), st.tri_tests_shadow / max(1, st.rays_shadow)))
+    d = list(st.diag)
+    print("   interior loop: closest %d wave trips with %.1f lanes busy; shadow %d wave trips with %.1f lanes busy" % (d[0], d[1] / max(1, d[0]), d[3], d[4] / max(1, d[3])))
     ctx.set_timing(1)
     for _ in range(3):
         ctx.trace(wl.width, wl.height)
@@ -30,4 +34,4 @@ for on in (1, 0, 1, 0):
         ms.append((s2.ms_frame, s2.ms_raygen, s2.ms_trace_closest, s2.ms_shade, s2.ms_tail, s2.ms_trace_shadow, s2.ms_resolve))
     ctx.set_timing(0)
     print("   lone frame %.3f ms: cover+entry+raygen %.3f  closest %.3f  shade %.3f  tail %.3f  shadow %.3f  resolve %.3f" % tuple(np.median(np.array(ms), axis=0)))
-print("identical frames:", bool(np.array_equal(imgs[0], imgs[1])))
+print("identical frames:", bool(np.array_equal(imgs[0], imgs[1])) and bool(np.array_equal(imgs[0], imgs[2])))

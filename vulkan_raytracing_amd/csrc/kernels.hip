@@ -1446,7 +1446,8 @@ struct ShadeArgs {
 
 // TILE: bounce 0 of a frame with tile blobs — the hit records lie in two regions per shard (kernels_tile.inc)
 // BATCH: the frame is one of a frame batch — the light is the one of the sample's frame (the single-frame instantiations are untouched)
-template <bool TILE = false, bool BATCH = false>
+// RUNS: bounce 0 of a frame with shadow runs (kernels_beam.inc) — the shadow ray of a primary hit goes into the slot of its primary ray
+template <bool TILE = false, bool BATCH = false, bool RUNS = false>
 __device__ __forceinline__ void shade_body(const ShadeArgs& a, const int bounce) {
   const FrameDev& f = a.f;
   const UniformsDev& U = a.u;
@@ -1600,20 +1601,34 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a, const int bounce)
       st_stream(&f.ray_o[nxt][v], make_float4(no.x, no.y, no.z, 10000.0f));
       st_stream(&f.ray_d[nxt][v], make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid)));
     }
-    const uint32_t slot_s = wave_alloc(push_shadow, f.counters + cnt_tail(Q_SHADOW, (int)shard));
-    if (push_shadow) {
-      const uint32_t v = shard * f.shard_cap + slot_s;
-      st_stream(&f.sh_o[v], make_float4(no.x, no.y, no.z, sh_tmax));
-      st_stream(&f.sh_d[v], make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid)));
-      st_stream(&f.sh_c[v], make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w));
-      if (f.sh_e != nullptr) f.sh_e[v] = sh_ent;
+    if (RUNS) {
+      // shadow runs: no allocation — the ray's place is its primary ray's; every slot of the run says whether it holds one
+      if (base + lane < n) {
+        if (push_shadow) {
+          st_stream(&f.sh_o[q], make_float4(no.x, no.y, no.z, sh_tmax));
+          st_stream(&f.sh_c[q], make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w));
+          if (f.sh_e != nullptr) f.sh_e[q] = sh_ent;
+        }
+        st_stream(&f.sh_d[q], push_shadow ? make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid)) : make_float4(0.f, 0.f, 0.f, __uint_as_float(SID_DEAD)));
+      }
+      const uint64_t m_sh = __ballot(push_shadow);   // (statistics: a non-returning atomic)
+      if (lane == 0 && m_sh != 0ull) __hip_atomic_fetch_add(f.counters + cnt_tail(Q_SHADOW0, (int)shard), (uint32_t)__builtin_popcountll(m_sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const uint32_t slot_s = wave_alloc(push_shadow, f.counters + cnt_tail(Q_SHADOW, (int)shard));
+      if (push_shadow) {
+        const uint32_t v = f.sh_base + shard * f.shard_cap + slot_s;   // (sh_base: above the shadow runs of bounce 0, when the frame has them)
+        st_stream(&f.sh_o[v], make_float4(no.x, no.y, no.z, sh_tmax));
+        st_stream(&f.sh_d[v], make_float4(nd.x, nd.y, nd.z, __uint_as_float(sid)));
+        st_stream(&f.sh_c[v], make_float4(sh_c.x, sh_c.y, sh_c.z, sh_w));
+        if (f.sh_e != nullptr) f.sh_e[v] = sh_ent;
+      }
     }
   }
   }
 }
 
-template <bool TILE, bool BATCH>
-__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body<TILE, BATCH>(a, a.bounce); }
+template <bool TILE, bool BATCH, bool RUNS = false>
+__global__ __launch_bounds__(256) void k_shade(ShadeArgs a) { shade_body<TILE, BATCH, RUNS>(a, a.bounce); }
 
 // ------------------------------------------------------------------------------------------------
 // k_tail: bounces first..maxBounceCount of one frame in ONE launch.  After the first bounce a frame usually
@@ -1719,7 +1734,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
       else if (t >= STAT_BLOB && t < STAT_BLOB + 5) v = ld_cursor(f.counters + CNT_BLOB_STATS + (int)(t - STAT_BLOB));
       else if (t >= STAT_TILE_DIAG && t < STAT_TILE_DIAG + 6) v = cnt64(CNT_TILE_DIAG + 2 * (int)(t - STAT_TILE_DIAG));
       else if (t == STAT_SECONDARY) { for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) v += s_q[b]; }
-      else if (t == STAT_SHADOW) v = s_q[Q_SHADOW];
+      else if (t == STAT_SHADOW) v = s_q[Q_SHADOW] + s_q[Q_SHADOW0];
       else if (t == STAT_QUEUE1) v = s_q[1];
       else if (t == STAT_FAULT) v = ld_cursor(f.counters + CNT_FAULT);
       else if (t == STAT_FAULT_TOTAL) {
@@ -1894,13 +1909,13 @@ void launch_entry(const SceneDev& sc, const EntryViews& a, hipStream_t s) {
 
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s) {
   TraceArgs a = make_args(sc, f.counters, Q_SHADOW, f.shard_cap, f.ovf_stack);
-  a.ray_o = f.sh_o; a.ray_d = f.sh_d; a.sh_c = f.sh_c;
+  a.ray_o = f.sh_o + f.sh_base; a.ray_d = f.sh_d + f.sh_base; a.sh_c = f.sh_c + f.sh_base;   // (sh_base: above the shadow runs of bounce 0, which k_beam_shadow walks)
   a.sample_color = f.sample_color;
 #ifdef RT_ALT_KERNELS
   if (cfg.packet != 0 && cfg.variant == 0) {
     // one wavefront per chunk of shadow rays (k_packet); optionally from the records of the cube around the light
     const bool le = f.light_entry != nullptr && f.sh_e != nullptr;
-    a.entry = le ? f.light_entry : nullptr; a.sh_e = le ? f.sh_e : nullptr;
+    a.entry = le ? f.light_entry : nullptr; a.sh_e = le ? f.sh_e + f.sh_base : nullptr;
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.packet_blocks), b(256);
     if (le) {
@@ -1915,7 +1930,7 @@ void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, c
 #endif
   if (f.light_entry != nullptr && f.sh_e != nullptr && cfg.variant == 0) {
     // shadow rays start at the record of their tile of the cube around the light (k_entry, k_shade)
-    a.entry = f.light_entry; a.sh_e = f.sh_e;
+    a.entry = f.light_entry; a.sh_e = f.sh_e + f.sh_base;
     a.rays_per_lane = (uint32_t)cfg.rays_per_lane; a.min_blocks = (uint32_t)cfg.min_blocks;
     const dim3 g(cfg.trace_blocks), b(256);
     if (counting) hipLaunchKernelGGL((k_trace_count<MODE_SHADOW, true, false, true>), g, b, 0, s, a);
@@ -1924,6 +1939,22 @@ void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, c
     return;
   }
   launch_trace<MODE_SHADOW, true>(a, counting, cfg, s);
+}
+
+// the shadow rays of the primary hits, one walk per pixel (kernels_beam.inc): the runs of bounce queue 0 in the shadow arrays
+void launch_beam_shadow(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, bool counting, const LaunchCfg& cfg, hipStream_t s) {
+  if (!f.shadow_runs || !f.pixel_runs) return;
+  BeamShadowArgs A{};
+  A.t = make_args(sc, f.counters, 0, f.shard_cap, f.ovf_stack);
+  A.t.work = f.counters + cnt_work(Q_SHADOW0, 0);
+  A.t.ray_o = f.sh_o; A.t.ray_d = f.sh_d; A.t.sh_c = f.sh_c; A.t.sample_color = f.sample_color;
+  const bool le = f.light_entry != nullptr && f.sh_e != nullptr;
+  A.t.entry = le ? f.light_entry : nullptr; A.t.sh_e = le ? f.sh_e : nullptr;
+  for (int k = 0; k < 3; k++) A.light[k] = u.light_position[k];
+  A.run = (uint32_t)f.pixel_runs;
+  const dim3 g(cfg.trace_blocks), b(256);
+  if (counting) hipLaunchKernelGGL(k_beam_shadow_count, g, b, 0, s, A);
+  else hipLaunchKernelGGL(k_beam_shadow, g, b, 0, s, A);
 }
 
 void launch_trace_raw(const SceneDev& sc, const float4* ray_o, const float4* ray_d, HitRec* out, uint32_t shard_cap,
@@ -1987,6 +2018,7 @@ void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, co
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int bounce, const LaunchCfg& cfg, hipStream_t s) {
   ShadeArgs a{sc, f, u, bounce, bt};
   if (f.batch_k > 1) hipLaunchKernelGGL((k_shade<false, true>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
+  else if (bounce == 0 && f.shadow_runs) hipLaunchKernelGGL((k_shade<false, false, true>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
   else if (bounce == 0 && f.tile_blob != nullptr) hipLaunchKernelGGL((k_shade<true, false>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((k_shade<false, false>), dim3(cfg.shade_blocks), dim3(256), 0, s, a);
 }

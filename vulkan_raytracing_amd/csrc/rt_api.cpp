@@ -207,6 +207,9 @@ struct rt_ctx {
   size_t entry_alloc_tiles = 0;
   // tile blobs (rt_device.h; kernels_tile.inc): 1 = k_blob writes, for every tile whose record names an instance, the nodes and triangle packets the tile's beam
   // can touch as one blob, and k_trace_tile walks the tile's primary rays through it in LDS (result-identical; needs entry_points)
+  int shadow_beams = 0; // ... and the shadow rays of the primary hits (k_beam_shadow): result-identical, a third of the node visits, and SLOWER (the rays of a pixel end
+                        // at very different times — the first hit ends a ray — so most lanes of a wave wait: profiles/r04_experiments.txt); rt_set_param("shadow_beams", 1)
+  bool sh_double = false;   // the shadow arrays of this context's frame have room for the shadow runs beside the compact queue
   int pixel_beams = 1;  // the primary rays of a pixel walked together (kernels_beam.inc): result-identical; rt_set_param("pixel_beams", 0) restores one walk per ray
   int tile_blobs = 0;   // OFF by default: result-identical and measured slower (profiles/r04_experiments.txt: a wave of k_tile spends two thirds of its life
                         // fetching its blob and storing its results, the walk itself is 2.6 x faster than the global one)
@@ -734,17 +737,25 @@ int ensure_common(rt_ctx* c) {
 
 int ensure_frame(rt_ctx* c, size_t capacity) {
   int r = ensure_common(c); if (r) return r;
-  if (capacity <= c->frame_capacity) return RT_OK;
+  const bool want_double = c->shadow_beams != 0;
+  if (capacity <= c->frame_capacity && (!want_double || c->sh_double)) return RT_OK;
+  capacity = std::max(capacity, c->frame_capacity);
   FrameDev& f = c->frame;
-  void** ptrs[] = {(void**)&f.ray_o[0], (void**)&f.ray_o[1], (void**)&f.ray_d[0], (void**)&f.ray_d[1], (void**)&f.hit_a,
-                   (void**)&f.sh_o, (void**)&f.sh_d, (void**)&f.sh_c, (void**)&f.sample_color};
+  void** ptrs[] = {(void**)&f.ray_o[0], (void**)&f.ray_o[1], (void**)&f.ray_d[0], (void**)&f.ray_d[1], (void**)&f.hit_a, (void**)&f.sample_color};
+  // (the shadow arrays hold two regions: the shadow runs of bounce 0 in their primary rays' slots — kernels_beam.inc — and the compact
+  // queue of the later bounces above them)
+  void** sh_ptrs[] = {(void**)&f.sh_o, (void**)&f.sh_d, (void**)&f.sh_c};
   for (void** p : ptrs) { if (*p) HIP_TRY(c, hipFree(*p)); *p = nullptr; }
+  for (void** p : sh_ptrs) { if (*p) HIP_TRY(c, hipFree(*p)); *p = nullptr; }
   if (f.hit_inst) { HIP_TRY(c, hipFree(f.hit_inst)); f.hit_inst = nullptr; }
   if (f.sh_e) { HIP_TRY(c, hipFree(f.sh_e)); f.sh_e = nullptr; }
   c->frame_capacity = 0;
   for (void** p : ptrs) HIP_TRY(c, hipMalloc(p, capacity * sizeof(float4)));
+  const size_t sh_cap = (want_double ? 2 : 1) * capacity;
+  for (void** p : sh_ptrs) HIP_TRY(c, hipMalloc(p, sh_cap * sizeof(float4)));
   HIP_TRY(c, hipMalloc((void**)&f.hit_inst, capacity * sizeof(int32_t)));
-  HIP_TRY(c, hipMalloc((void**)&f.sh_e, capacity * sizeof(uint32_t)));
+  HIP_TRY(c, hipMalloc((void**)&f.sh_e, sh_cap * sizeof(uint32_t)));
+  c->sh_double = want_double;
   c->frame_capacity = capacity;
   return RT_OK;
 }
@@ -1011,6 +1022,8 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   cfg.far = far_frame ? 1 : 0;
   f.far_possible = cfg.far;
   f.pixel_runs = beam_on ? 64 * (int)std::min<uint32_t>(u.samples_per_pixel, 4u) : 0;
+  f.shadow_runs = (beam_on && c->shadow_beams && K == 1 && std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2])) ? 1u : 0u;   // (a frame batch has a light per frame: one walk per shadow ray there)
+  f.sh_base = f.shadow_runs ? (uint32_t)capacity : 0u;
   if (c->jitter_table && rows > 0) { r = jitter_table_for(c, f, u.samples_per_pixel, s, &f.jitter); if (r) return r; }
   // timing spans accumulate over frames until rt_get_stats reads (and averages) them; without a reader the
   // pool is recycled every 64 frames
@@ -1087,7 +1100,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
       }
     }
     { LaunchCfg cs = cfg; if (cap_shadow > 0) cs.trace_blocks = std::min(cfg.trace_blocks, c->n_cu * cap_shadow);
-      Span sp(c, CAT_SHADOW, s); launch_trace_shadow(sc, f, c->counting, cs, s); }
+      Span sp(c, CAT_SHADOW, s); launch_beam_shadow(sc, f, u, c->counting, cs, s); launch_trace_shadow(sc, f, c->counting, cs, s); }
     { Span sp(c, CAT_RESOLVE, s); launch_resolve(f, u, s); }
   }
   HIP_TRY(c, hipGetLastError());
@@ -1242,7 +1255,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->shadow_beams = parent->shadow_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1604,6 +1617,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "jitter_table") { c->jitter_table = value != 0; return RT_OK; }
   if (k == "tile_blobs") { c->tile_blobs = value != 0; return RT_OK; }
   if (k == "pixel_beams") { c->pixel_beams = value != 0; return RT_OK; }
+  if (k == "shadow_beams") { c->shadow_beams = value != 0; return RT_OK; }
 
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }
   if (k == "packet_trace") {

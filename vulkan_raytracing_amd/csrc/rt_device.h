@@ -199,7 +199,8 @@ constexpr int HIT_DEAD = -2;                       // hit_inst of a slot of the 
 constexpr int Q_BLOB = CNT_MAX_BOUNCES + 2;        // tail = slots handed out in sub-arena `shard` (k_blob); work unused
 constexpr int Q_BLOB_LIST = CNT_MAX_BOUNCES + 3;   // + class: tail = blobs of that class in list part `shard`
 constexpr int Q_DEAD = Q_BLOB_LIST + BLOB_CLASSES;  // pixel runs (kernels_beam.inc): tail = slots of bounce queue 0 that hold no ray (statistics)
-constexpr int N_QUEUES = Q_DEAD + 1;
+constexpr int Q_SHADOW0 = Q_DEAD + 1;               // pixel runs: tail = shadow rays of bounce 0 (they sit in their primary rays' slots; statistics), work = run cursors of k_beam_shadow
+constexpr int N_QUEUES = Q_SHADOW0 + 1;
 constexpr int TAIL_BLOCKS = 64;                // largest grid of k_tail (rt_api clamps it to the device: tail_grid())
 constexpr int MAX_TAILS_IN_FLIGHT = 16;        // k_tail launches (frame slots) that must be co-resident on one GPU at any time
 constexpr uint32_t TAIL_MAX_RAYS = 16384;      // bounces whose queue was larger in the previous frame get their own full-grid launches (k_tail then has at most one ray per lane: a 64-workgroup grid walks 26 k rays in 0.37 ms, the full grid in 0.05)

@@ -87,6 +87,10 @@ struct FrameDev {
   // slots per sample row of its k_raygen workgroup (slot = run + 64 * row + pixel of the tile), so that k_beam finds the samples of a
   // pixel together; a slot without a ray has a zero direction and gets HIT_DEAD as its hit record.
   int pixel_runs;
+  // ... and the shadow ray of a primary hit takes the slot of its primary ray in sh_o / sh_d / sh_c / sh_e (zero direction: none), for
+  // k_beam_shadow; the compact shadow queue of the later bounces then starts sh_base entries up in the same arrays (0: no shadow runs)
+  uint32_t shadow_runs;        // 0 / 1
+  uint32_t sh_base;
 };
 
 // camera of k_cover: the inverse of the basis (right, up, forward) maps a world offset v = P - position to (a.x, a.y, a.z) with
@@ -156,6 +160,7 @@ void launch_tile(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, bo
 // bounces first_bounce..maxBounceCount (traversal + shading) in one launch of TAIL_BLOCKS workgroups
 void launch_tail(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int first_bounce, bool counting, const LaunchCfg& cfg, int tail_blocks, hipStream_t s);
 void launch_shade(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, const BatchTab& bt, int bounce, const LaunchCfg& cfg, hipStream_t s);
+void launch_beam_shadow(const SceneDev& sc, const FrameDev& f, const UniformsDev& u, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_trace_shadow(const SceneDev& sc, const FrameDev& f, bool counting, const LaunchCfg& cfg, hipStream_t s);
 void launch_resolve(const FrameDev& f, const UniformsDev& u, hipStream_t s);
 // marks the tiles of `mask` (FrameDev::cover layout) that the frontier boxes of the instances project onto
