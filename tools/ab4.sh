@@ -1,10 +1,11 @@
 #!/bin/bash
 # round-4 A/B helper: one line per (label, bench args) in the driver's form and, optionally, the lone-frame breakdown — all inside ONE gpurun
-# call so that the box (clocks differ by up to 10 % between boxes) is the same.  Usage: tools/ab4.sh <outfile> "label|bench args" ...
+# call so that the box (clocks differ by up to 10 % between boxes) is the same.  Usage: tools/ab4.sh <outfile> "label|bench args[|ENV=value ...]" ...
 out=$1; shift
 for spec in "$@"; do
-  label=${spec%%|*}; args=${spec#*|}
-  python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $args > gpurun_out/ab4_tmp.json 2> gpurun_out/ab4_tmp.err || { echo "$label: bench FAILED"; tail -5 gpurun_out/ab4_tmp.err; continue; }
+  label=${spec%%|*}; rest=${spec#*|}; args=${rest%%|*}; envs=""
+  if [ "$rest" != "$args" ]; then envs=${rest#*|}; fi      # optional third field: environment assignments (e.g. RT_LIB_VARIANT=name)
+  env $envs python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline $args > gpurun_out/ab4_tmp.json 2> gpurun_out/ab4_tmp.err || { echo "$label: bench FAILED"; tail -5 gpurun_out/ab4_tmp.err; continue; }
   python3 - "$label" <<'PY' | tee -a "$out"
 import json, sys
 d = json.loads(open("gpurun_out/ab4_tmp.json").read().strip().splitlines()[-1])

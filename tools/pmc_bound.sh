@@ -26,7 +26,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"].replace("rt::","")
-        if "k_trace" in k or "k_shade" in k or "k_raygen" in k or "k_tail" in k or "k_resolve" in k:
+        if "k_trace" in k or "k_beam" in k or "k_shade" in k or "k_raygen" in k or "k_tail" in k or "k_resolve" in k:
             agg[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out={}
 for k,cs in sorted(agg.items()):

@@ -21,7 +21,7 @@ agg=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k=r["Kernel_Name"]
-        if "k_trace" in k or "k_shade" in k or "k_raygen" in k:
+        if "k_trace" in k or "k_beam" in k or "k_shade" in k or "k_raygen" in k:
             agg[k.replace("rt::","")[:48]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k,cs in sorted(agg.items()):
     print(k)

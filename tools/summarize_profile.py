@@ -54,7 +54,7 @@ def main():
     # (a context's first frame also launches the same instantiations on its small later bounces; those are left out: < half the longest)
     print("== full-size launches of the traversal kernels (the averages latest_profile.json carries) ==")
     for k, v in sorted(tr.items(), key=lambda kv: -sum(kv[1])):
-        if "k_trace<" not in k and "k_tile<" not in k:
+        if "k_trace<" not in k and "k_tile<" not in k and "k_beam" not in k:
             continue
         durs = sorted(v)
         big = [x for x in durs if x >= 0.5 * durs[-1]]
@@ -79,10 +79,10 @@ def main():
     pm = res.get("pmc", {})
 
     def is_closest(k):
-        return "k_trace<0, false, false" in k or "k_trace4<0, false, false" in k or "k_packet<0, false, false" in k
+        return "k_trace<0, false, false" in k or "k_trace4<0, false, false" in k or "k_packet<0, false, false" in k or "k_beam(" in k or k.endswith("k_beam")
 
     def is_shadow(k):
-        return "k_trace<1, true, false" in k or "k_trace4<1, true, false" in k or "k_packet<1, true, false" in k
+        return "k_trace<1, true, false" in k or "k_trace4<1, true, false" in k or "k_packet<1, true, false" in k or "k_beam_shadow" in k
 
     def traffic(pred, label, key):
         # the instantiation that does the work (entry records: k_trace<..., true>); a context's first frame also launches the plain one on its small later bounces
