@@ -651,6 +651,9 @@ def main(args):
                                               "of the pipeline; a rank's 1/N shard of ONE frame is eight launches at their latency floors" % rig.K,
                              "primary_rays": "one walk per pixel (k_beam: the samples of a pixel share the camera as origin; boxes against their beam, triangles per ray: "
                                              "hit records bit-identical to one walk per ray); mean_node_visits_per_ray counts a pixel's walk once",
+                             "shadow_rays": "a shadow ray is not walked when the light adds exactly nothing to its sample whether it arrives or not (surface and half vector "
+                                            "face away from the light: diffuse = specular = 0, src/shader.rgen:113-128, same bits either way) - k_shade settles it; it counts in "
+                                            "`value` like every traceRayEXT of the reference (rays_traversed_per_frame says how many were walked); --param dead_shadow_rays=0 walks them all",
                              "animated_loop": "per step: animate (fixed dt 1/60 s) -> rt_set_instances(update=1) = TLAS refit -> rt_set_uniforms -> frame; src/main.cpp:2836-2861, 2901-2903",
                              "kept_between_frames": "what depends on the light, the instances and the trees only, as in the reference: BLAS, TLAS, and (rt_set_param shadow_entry 2, "
                                                     "the default) the shadow rays' entry records around the light, rebuilt when the light or an instance moves — the timed "
@@ -703,7 +706,7 @@ def main(args):
                 "rocprof": None, "hbm_measured": None}
         # the two traversal kernels together over WALL time: with P frames in flight their launches overlap, so the per-launch
         # figure above (duration stretched by the other frames' kernels) understates what the chip delivers
-        sh_rays = cst.rays_shadow
+        sh_rays = cst.rays_shadow - cst.rays_shadow_untraced     # the shadow rays that are walked (the others: config.shadow_rays)
         sh_bytes = sh_rays * (48 + 16) + cst.node_visits_shadow * cst.bvh_node_bytes + cst.tri_tests_shadow * cst.bvh_tri_bytes
         cl_bytes = cst.closest_rays * (RAY_BYTES + HIT_BYTES) + cst.node_visits * cst.bvh_node_bytes + cst.tri_tests * cst.bvh_tri_bytes
         if n == 1:
@@ -778,13 +781,15 @@ def main(args):
         # what `value` is made of: most primary rays are shaded as misses inside k_raygen (coverage mask, empty entry records, TLAS
         # boxes) and never enter a traversal kernel.  value_traversed counts only the rays that did.
         if n == 1:
-            traversed = cst.closest_rays + cst.rays_shadow
+            traversed = cst.closest_rays + cst.rays_shadow - cst.rays_shadow_untraced
             result["value_traversed"] = traversed / (result["ms_per_step"] * 1e-3) / 1e6
-            result["rays_traversed_per_frame"] = {"closest_hit_kernels": int(cst.closest_rays), "shadow_kernel": int(cst.rays_shadow),
+            result["rays_traversed_per_frame"] = {"closest_hit_kernels": int(cst.closest_rays), "shadow_kernel": int(cst.rays_shadow - cst.rays_shadow_untraced),
+                                                  "shadow_rays_settled_in_k_shade": int(cst.rays_shadow_untraced),
                                                   "primary_rays_ended_in_raygen": int(rays_frame[0] - (cst.closest_rays - cst.rays_secondary)),
                                                   "share_of_primary_rays_ended_in_raygen": (rays_frame[0] - (cst.closest_rays - cst.rays_secondary)) / max(1, rays_frame[0]),
                                                   "definition": "value_traversed = (rays through k_trace<closest>/k_tail + rays through k_trace<shadow>) / ms_per_step, Mrays/s; "
-                                                                "value counts one ray per traceRayEXT-equivalent, including the primary rays whose miss k_raygen settles"}
+                                                                "value counts one ray per traceRayEXT-equivalent, including the primary rays whose miss k_raygen settles and the shadow rays "
+                                                                "whose outcome cannot change their sample (settled in k_shade)"}
         result["roofline"] = roof
         if last_frame is not None:
             img = last_frame.cpu().numpy()
@@ -838,7 +843,8 @@ def main(args):
             result["other_mesh"] = {"mesh": wl2.mesh_label, "value": st2.rays_total * args.steps / dt2 / 1e6, "unit": "Mrays/s", "ms_per_step": dt2 / args.steps * 1e3,
                                     "rays_per_frame": {"primary": st2.rays_primary, "secondary": st2.rays_secondary, "shadow": st2.rays_shadow},
                                     "mean_node_visits_per_ray": c2.node_visits / max(1, c2.closest_rays), "mean_tri_tests_per_ray": c2.tri_tests / max(1, c2.closest_rays),
-                                    "mean_node_visits_per_shadow_ray": c2.node_visits_shadow / max(1, c2.rays_shadow)}
+                                    "mean_node_visits_per_shadow_ray": c2.node_visits_shadow / max(1, c2.rays_shadow - c2.rays_shadow_untraced),
+                                    "shadow_rays_settled_in_k_shade": int(c2.rays_shadow_untraced)}
             rig2.close()
             mark("other mesh done")
         if n == 1 and not args.no_cpu_baseline:

@@ -124,6 +124,8 @@ typedef struct rt_stats {
   uint64_t tile_rays_handed_on; /* ... of which went on to the global walk because they could still hit another instance */
   uint64_t tile_diag[6];        /* counting builds: wave cycles of k_tile before the walk (blob copy, ray generation), in the walk, in all; then from the
                                    start of the workgroup until: its list entry is there, the blob is in LDS, the ray is set up */
+  uint64_t rays_shadow_untraced; /* ABI 7 — of rays_shadow: shadow rays whose outcome cannot change their sample (the surface and the half vector face away from
+                                    the light: diffuse and specular are exactly 0, src/shader.rgen:113-128) — settled in k_shade, not walked (rt_set_param "dead_shadow_rays") */
 } rt_stats;
 
 /* Device/queue/pipeline creation (src/main.cpp:928-1102, 1578-1601).  device_id = HIP ordinal. */

@@ -1619,6 +1619,61 @@ def test_pixel_beams_are_result_identical(ctx):
     both(256, 256)
 
 
+def test_shadow_rays_that_cannot_change_their_sample_are_settled_in_k_shade(ctx):
+    """src/shader.rgen:107-128 traces a shadow ray for every diffuse hit and adds `pow(0.9, i) * (diffuse + specular)` if the light is
+    visible.  Where the surface AND the half vector face away from the light both terms are exactly 0: tmpColor stays Iamb*ka whether the
+    ray reaches the light or not, bit for bit — k_shade writes the sample and does not queue the ray (rt_set_param "dead_shadow_rays",
+    default on; rt_stats.rays_shadow still counts it, rays_shadow_untraced says how many).  Frames and ray counts are identical with the
+    parameter on and off and equal the oracle's, with and without a material table (Iamb*ka of the hit's material), with the shadow
+    rays in beams, on the kernels of the alternative library's default path, and in the bounce loop (mirror teapot: k_tail)."""
+    arm, _ = host.armadillo_path(RES)
+    W, H = 408, 232
+
+    def both(tag):
+        out = {}
+        ctx.trace(W, H)      # (so that both frames below find the light-side entry records of this scene kept)
+        for on in (1, 0):
+            ctx.set_param("dead_shadow_rays", on)
+            img, st = ctx.trace(W, H, counting=True)
+            out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.rays_shadow_untraced, st.node_visits_shadow)
+        ctx.set_param("dead_shadow_rays", 1)
+        assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1], (tag, out[1][1], out[0][1])
+        assert out[0][2] == 0 and 0 < out[1][2] < out[1][1][2], (tag, out[1][2], out[1][1])
+        assert out[1][3] < out[0][3], (tag, out[1][3], out[0][3])       # fewer shadow rays walked
+        return out
+
+    try:
+        sp = scenes.two_object_scene(os.path.join(RES, "teapot.obj"), arm, 1, 0, 2, 3, sky=scenes.synthetic_skybox(64), ctx=ctx, time_param=0.45)
+        o = both("diffuse mesh behind a mirror teapot")
+        ref, rc = sp.orc.render(W, H)
+        check_image(o[1][0], ref)
+        assert o[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        ctx.set_param("shadow_beams", 1)
+        both("shadow beams")
+        ctx.set_param("shadow_beams", 0)
+        # the light on the far side: most visible surfaces face away from it
+        u = sp.uniforms.copy(); u[0]["light_position"][:3] = (-6.0, -3.0, -20.0)
+        sp.set_uniforms(u)
+        o2 = both("light behind the scene")
+        assert o2[1][2] > 0.3 * o2[1][1][2], (o2[1][2], o2[1][1])
+        ref, rc = sp.orc.render(W, H)
+        check_image(o2[1][0], ref)
+        assert o2[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+        # a material table: the settled colour is Iamb*ka of the hit's material
+        inst = [host.make_instance(np.array([1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0], np.float32), 0, 0)]
+        um = host.default_uniforms(max_bounce_count=2, samples_per_pixel=2, center_object_type=0, orbiting_object_type=0)
+        spm = scenes.ScenePair([os.path.join(RES, "cube_scene.obj")], inst, um, sky=scenes.synthetic_skybox(64), ctx=ctx)
+        spm.set_materials(spm.geom.materials, spm.geom.prim_material)
+        W, H = 256, 256
+        om = both("materials")
+        ref, rc = spm.orc.render(W, H)
+        check_image(om[1][0], ref)
+        assert om[1][1] == (int(rc[0]), int(rc[1]), int(rc[2]))
+    finally:
+        ctx.set_param("dead_shadow_rays", 1); ctx.set_param("shadow_beams", 0)
+        ctx.set_materials(None)
+
+
 def test_jitter_table_is_bit_identical_to_evaluating_the_hash(ctx):
     """k_raygen reads (ux, uy) of every sample from a table computed once per (width, height, spp, shard layout)
     by the same device function (kernels.hip sample_uv / k_jitter_table) instead of evaluating two binary64 sines per sample and

@@ -27,7 +27,7 @@ def test_c_abi_exports_every_declared_symbol():
     L = api.lib()
     for name in declared:
         assert hasattr(L, name), name
-    assert L.rt_abi_version() == 6
+    assert L.rt_abi_version() == 7
     assert L.rt_shard_rows(1080, 8, 0, 8) == tiling.shard_rows(1080, 8, 0, 8)
 
 

@@ -23,6 +23,7 @@ for on in (1, 0, 2, 1, 0, 2):      # 2: pixel beams for the primary rays only
     print("beams=%d counting: closest rays %d  node visits %d (%.2f per closest ray)  triangle tests %d (%.2f)  | shadow rays %d  node visits %.2f per ray  triangle tests %.2f" % (
         on, st.closest_rays, st.node_visits, st.node_visits / max(1, st.closest_rays), st.tri_tests, st.tri_tests / max(1, st.closest_rays),
         st.rays_shadow, st.node_visits_shadow / max(1, st.rays_shadow), st.tri_tests_shadow / max(1, st.rays_shadow)))
+    print("   shadow rays settled in k_shade (their outcome cannot change the sample): %d of %d" % (st.rays_shadow_untraced, st.rays_shadow))
     d = list(st.diag)
     print("   interior loop: closest %d wave trips with %.1f lanes busy; shadow %d wave trips with %.1f lanes busy" % (d[0], d[1] / max(1, d[0]), d[3], d[4] / max(1, d[3])))
     ctx.set_timing(1)

@@ -28,7 +28,7 @@ class RtStats(C.Structure):
                 ("launches_trace_closest", C.c_uint32), ("launches_total", C.c_uint32), ("timed_frames", C.c_uint32), ("ms_tail", C.c_float),
                 ("bvh_node_bytes", C.c_uint32), ("bvh_tri_bytes", C.c_uint32), ("tail_faults", C.c_uint32), ("frames_rerendered", C.c_uint32),
                 ("blob_tiles", C.c_uint64), ("blob_tiles_large", C.c_uint64), ("blob_tiles_refused", C.c_uint64), ("blob_nodes", C.c_uint64), ("blob_tris", C.c_uint64),
-                ("tile_rays", C.c_uint64), ("tile_rays_handed_on", C.c_uint64), ("tile_diag", C.c_uint64 * 6)]
+                ("tile_rays", C.c_uint64), ("tile_rays_handed_on", C.c_uint64), ("tile_diag", C.c_uint64 * 6), ("rays_shadow_untraced", C.c_uint64)]
 
     def as_dict(self):
         return {k: (list(getattr(self, k)) if k in ("diag", "tile_diag") else getattr(self, k)) for k, _ in self._fields_}

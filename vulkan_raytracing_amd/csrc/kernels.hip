@@ -1476,7 +1476,7 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a, const int bounce)
     for (int t = 0; t < N_SHARDS; t++) n = (shard == (uint32_t)t) ? cnt[t] : n;
     if (base >= n) continue;
     const uint32_t q = shard * f.shard_cap + ((TILE && pass) ? f.shard_cap - n : 0u) + base + lane;
-    bool push_next = false, push_shadow = false;
+    bool push_next = false, push_shadow = false, settled = false;   // settled: a shadow ray whose outcome cannot change the sample
     F3 no = mk3(0, 0, 0), nd = mk3(0, 0, 1);
     float sh_tmax = 0.f; F3 sh_c = mk3(0, 0, 0); float sh_w = 0.f;
     uint32_t sh_ent = ENTRY_FROM_ROOT;
@@ -1542,9 +1542,19 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a, const int bounce)
             const F3 diff = mk3((Iv * kd.x) * dl, (Iv * kd.y) * dl, (Iv * kd.z) * dl);
             const F3 spec = mk3((Iv * ks.x) * sp, (Iv * ks.y) * sp, (Iv * ks.z) * sp);
             // tmpColor += pow(0.9, i) * (diffuse + specular) on top of Iamb*ka; the shadow kernel writes it if the light is visible
-            sh_c = fma3(w, add3(diff, spec), ambient_of(a.sc, mat)); sh_w = __uint_as_float(mat);
+            const F3 amb = ambient_of(a.sc, mat);
+            sh_c = fma3(w, add3(diff, spec), amb); sh_w = __uint_as_float(mat);
             nd = L; sh_tmax = dist;
             push_shadow = true;
+            // A surface that faces away from the light (and whose half vector does too) gets NOTHING from it: diffuse and specular are
+            // exactly 0 and tmpColor stays Iamb*ka whether the shadow ray finds the light or not (src/shader.rgen:113-128) — the sample's
+            // colour is the same bits either way, so the ray need not be walked.  It still counts as a shadow ray (the reference issues
+            // the traceRayEXT); rt_stats::rays_shadow_untraced says how many were settled here.
+            if (f.settle_dead_shadow_rays && __float_as_uint(sh_c.x) == __float_as_uint(amb.x) && __float_as_uint(sh_c.y) == __float_as_uint(amb.y) &&
+                __float_as_uint(sh_c.z) == __float_as_uint(amb.z)) {
+              st_stream(&f.sample_color[sid], make_float4(amb.x, amb.y, amb.z, 1.0f));
+              push_shadow = false; settled = true;
+            }
             if (f.light_entry != nullptr) {
               // which tile of the cube around the light does this ray belong to?  Seen from the light the ray's ORIGIN lies in
               // direction v; the ray then runs to within 0.01 of the light (k_entry's beams are widened by that much).
@@ -1592,6 +1602,13 @@ __device__ __forceinline__ void shade_body(const ShadeArgs& a, const int bounce)
           push_next = false;
           st_stream(&f.sample_color[sid], make_float4(0.08f, 0.24f, 0.08f, 1.0f));
         }
+      }
+    }
+    {
+      const uint64_t m_st = __ballot(settled);   // (statistics: non-returning atomics)
+      if (lane == 0 && m_st != 0ull) {
+        __hip_atomic_fetch_add(f.counters + cnt_tail(Q_SHADOW0, (int)shard), (uint32_t)__builtin_popcountll(m_st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(f.counters + cnt_work(Q_DEAD, (int)shard), (uint32_t)__builtin_popcountll(m_st), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     // wavefront ballot compaction into the next-bounce queue / the shadow queue of the same shard
@@ -1735,6 +1752,7 @@ __global__ __launch_bounds__(256) void k_resolve(FrameDev f, UniformsDev u) {
       else if (t >= STAT_TILE_DIAG && t < STAT_TILE_DIAG + 6) v = cnt64(CNT_TILE_DIAG + 2 * (int)(t - STAT_TILE_DIAG));
       else if (t == STAT_SECONDARY) { for (uint32_t b = 1; b <= u.max_bounce_count && b < (uint32_t)CNT_MAX_BOUNCES; b++) v += s_q[b]; }
       else if (t == STAT_SHADOW) v = s_q[Q_SHADOW] + s_q[Q_SHADOW0];
+      else if (t == STAT_SHADOW_UNTRACED) { for (int k = 0; k < N_SHARDS; k++) v += ld_cursor(f.counters + cnt_work(Q_DEAD, k)); }
       else if (t == STAT_QUEUE1) v = s_q[1];
       else if (t == STAT_FAULT) v = ld_cursor(f.counters + CNT_FAULT);
       else if (t == STAT_FAULT_TOTAL) {

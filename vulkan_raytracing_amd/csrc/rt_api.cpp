@@ -207,6 +207,7 @@ struct rt_ctx {
   size_t entry_alloc_tiles = 0;
   // tile blobs (rt_device.h; kernels_tile.inc): 1 = k_blob writes, for every tile whose record names an instance, the nodes and triangle packets the tile's beam
   // can touch as one blob, and k_trace_tile walks the tile's primary rays through it in LDS (result-identical; needs entry_points)
+  int dead_shadow_rays = 1; // a shadow ray whose outcome cannot change its sample (diffuse and specular exactly 0) is settled in k_shade; 0: walked like the others
   int shadow_beams = 0; // ... and the shadow rays of the primary hits (k_beam_shadow): result-identical, a third of the node visits, and SLOWER (the rays of a pixel end
                         // at very different times — the first hit ends a ray — so most lanes of a wave wait: profiles/r04_experiments.txt); rt_set_param("shadow_beams", 1)
   bool sh_double = false;   // the shadow arrays of this context's frame have room for the shadow runs beside the compact queue
@@ -1021,6 +1022,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   if (c->stack_need > 120) cfg.packet = 0;   // deeper than k_packet's 128-entry wave stack (a degenerate LBVH): the one-lane kernels spill to HBM instead
   cfg.far = far_frame ? 1 : 0;
   f.far_possible = cfg.far;
+  f.settle_dead_shadow_rays = c->dead_shadow_rays;
   f.pixel_runs = beam_on ? 64 * (int)std::min<uint32_t>(u.samples_per_pixel, 4u) : 0;
   f.shadow_runs = (beam_on && c->shadow_beams && K == 1 && std::isfinite(u.light_position[0]) && std::isfinite(u.light_position[1]) && std::isfinite(u.light_position[2])) ? 1u : 0u;   // (a frame batch has a light per frame: one walk per shadow ray there)
   f.sh_base = f.shadow_runs ? (uint32_t)capacity : 0u;
@@ -1122,7 +1124,7 @@ int collect_stats(rt_ctx* c) {
   st.rays_primary = c->last_primary;
   if (!c->last_empty) {
     st.rays_secondary = hs[STAT_SECONDARY];
-    st.rays_shadow = hs[STAT_SHADOW];
+    st.rays_shadow = hs[STAT_SHADOW]; st.rays_shadow_untraced = hs[STAT_SHADOW_UNTRACED];
     // k_tail faults: the never-reset total tells of EVERY frame of this context whose grid barrier gave up (its workgroups were not
     // co-resident: another process on the GPU, a partition smaller than the occupancy query promised) — also of frames enqueued
     // before the last one, whose own statistics a later k_resolve has overwritten.  Any fault keeps this context off k_tail from
@@ -1197,7 +1199,7 @@ int collect_stats(rt_ctx* c) {
 // ================================================================================================
 extern "C" {
 
-int rt_abi_version(void) { return 6; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials; 5: rt_stats::frames_rerendered, entry records, BGRA8
+int rt_abi_version(void) { return 7; }   // 2: rt_trace_async / rt_trace_wait; 3: rt_stats::tail_faults, rt_debug_sizing; 4: frame slots, rt_assemble_shards, materials; 5: rt_stats::frames_rerendered, entry records, BGRA8
 
 // Persistent traversal grid, workgroups per CU.  A lone context renders one frame at a time: the kernels are latency-bound and
 // 5 workgroups per CU (all the LDS admits) are fastest (cfg3: 1.00 ms vs 1.03 at 4, 1.28 at 2).  With several frame slots the
@@ -1255,7 +1257,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->shadow_beams = parent->shadow_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->dead_shadow_rays = parent->dead_shadow_rays; c->shadow_beams = parent->shadow_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1617,6 +1619,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "jitter_table") { c->jitter_table = value != 0; return RT_OK; }
   if (k == "tile_blobs") { c->tile_blobs = value != 0; return RT_OK; }
   if (k == "pixel_beams") { c->pixel_beams = value != 0; return RT_OK; }
+  if (k == "dead_shadow_rays") { c->dead_shadow_rays = value != 0; return RT_OK; }
   if (k == "shadow_beams") { c->shadow_beams = value != 0; return RT_OK; }
 
   if (k == "entry_points") { c->entry_points = value != 0; return RT_OK; }

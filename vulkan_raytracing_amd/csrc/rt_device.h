@@ -199,7 +199,8 @@ constexpr int HIT_DEAD = -2;                       // hit_inst of a slot of the 
 constexpr int Q_BLOB = CNT_MAX_BOUNCES + 2;        // tail = slots handed out in sub-arena `shard` (k_blob); work unused
 constexpr int Q_BLOB_LIST = CNT_MAX_BOUNCES + 3;   // + class: tail = blobs of that class in list part `shard`
 constexpr int Q_DEAD = Q_BLOB_LIST + BLOB_CLASSES;  // pixel runs (kernels_beam.inc): tail = slots of bounce queue 0 that hold no ray (statistics)
-constexpr int Q_SHADOW0 = Q_DEAD + 1;               // pixel runs: tail = shadow rays of bounce 0 (they sit in their primary rays' slots; statistics), work = run cursors of k_beam_shadow
+constexpr int Q_SHADOW0 = Q_DEAD + 1;               // tail = shadow rays that are not in the compact shadow queue (statistics): those of bounce 0 in their primary rays' slots (shadow runs),
+                                                    // and those settled in k_shade (also counted in work of Q_DEAD); work = run cursors of k_beam_shadow
 constexpr int N_QUEUES = Q_SHADOW0 + 1;
 constexpr int TAIL_BLOCKS = 64;                // largest grid of k_tail (rt_api clamps it to the device: tail_grid())
 constexpr int MAX_TAILS_IN_FLIGHT = 16;        // k_tail launches (frame slots) that must be co-resident on one GPU at any time
@@ -234,6 +235,7 @@ enum StatSlot : int {
   STAT_TILE_RAYS = 21,    // primary rays walked in LDS by k_tile
   STAT_CONT_RAYS = 22,    // ... of which handed on to the global walk
   STAT_TILE_DIAG = 23,    // 6 values: CNT_TILE_DIAG
+  STAT_SHADOW_UNTRACED = 29,   // shadow rays settled in k_shade: their outcome cannot change the sample (counted in STAT_SHADOW as well)
   STAT_WORDS = 32
 };
 constexpr int CNT_WORKS = CNT_TAILS + N_QUEUES * N_SHARDS * CNT_STRIDE;

@@ -69,6 +69,7 @@ struct FrameDev {
   uint32_t* sh_e;              // shadow queue: record index | ENTRY_REVERSE, or ENTRY_FROM_ROOT
   int light_tiles;
   int far_possible;            // LaunchCfg::far of this frame (k_raygen's TLAS test)
+  int settle_dead_shadow_rays; // k_shade does not queue a shadow ray whose outcome cannot change its sample (rt_set_param "dead_shadow_rays")
   // (ux, uy) of every sample of this frame size and shard layout (k_jitter_table; NULL: k_raygen evaluates the hash itself)
   const float2* jitter;
   // frame batch (rt_device.h BATCH_MAX): `rows` stays the rows of ONE frame's shard; the buffers hold batch_k of them back to back
