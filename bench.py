@@ -573,6 +573,21 @@ def main(args):
         ctx.set_timing(1)
     rig.single_frames()
 
+    # ---- the timed loop once more with EVERY shadow ray walked (rt_set_param dead_shadow_rays 0), informational: what the frame costs without
+    # the settlement of the shadow rays whose outcome cannot change their sample (config.shadow_rays) — same frames, bit for bit
+    walked_ms = None
+    if n == 1 and rig.K == 1 and not args.no_extras and not args.animate and not any(p.startswith("dead_shadow_rays=") for p in (args.param or [])):
+        for c in rig.ctxs:
+            c.set_timing(False)
+            c.set_param("dead_shadow_rays", 0)
+        walked_ms = rig.timed(args.steps, max(P, args.warmup)) / args.steps * 1e3
+        for c in rig.ctxs:
+            c.set_param("dead_shadow_rays", 1)
+        rig.run_frames(P)           # (every slot's last frame is a default one again)
+        rig.sync()
+        ctx.set_timing(1)
+        mark("all-shadow-rays-walked region done")
+
     # ---- the same frames in passes of 8 (rt_trace_shard_batch), single GPU, informational: `value` stays the frame-by-frame loop ------
     batched_info = None
     if n == 1 and rig.K == 1 and not args.no_extras and not args.animate:
@@ -640,6 +655,8 @@ def main(args):
                   "n_gpus": n, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
                   "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                   "animated_ms_per_step": anim_ms,
+                  "ms_per_step_all_shadow_rays_walked": walked_ms,     # the same loop with rt_set_param dead_shadow_rays 0 (config.shadow_rays)
+                  "value_all_shadow_rays_walked": (total_rays / walked_ms / 1e3) if walked_ms else None,
                   "animated_value": (anim_rays / anim_ms / 1e3) if anim_ms else None,   # Mrays/s of the animated loop (mean rays of its last frames)
                   "config": {"workload": wl.describe() + (" [animated loop timed]" if args.animate else ""), "mesh": wl.mesh_label,
                              "rays_per_frame": {"primary": rays_frame[0], "secondary": rays_frame[1], "shadow": rays_frame[2]},
