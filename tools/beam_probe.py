@@ -26,6 +26,9 @@ for on in (1, 0, 2, 1, 0, 2):      # 2: pixel beams for the primary rays only
     print("   shadow rays settled in k_shade (their outcome cannot change the sample): %d of %d" % (st.rays_shadow_untraced, st.rays_shadow))
     d = list(st.diag)
     print("   interior loop: closest %d wave trips with %.1f lanes busy; shadow %d wave trips with %.1f lanes busy" % (d[0], d[1] / max(1, d[0]), d[3], d[4] / max(1, d[3])))
+    td = list(st.tile_diag)
+    if on and td[2]:
+        print("   k_beam runs: %d; node visits of the longest pixel of a run: mean %.1f, of the frame: %d (mean pixel: %.1f)" % (td[2], td[1] / td[2], td[0], st.node_visits / max(1.0, st.closest_rays / 4.0)))
     ctx.set_timing(1)
     for _ in range(3):
         ctx.trace(wl.width, wl.height)
