@@ -109,7 +109,7 @@ def mark(msg):
 def kernels_sha16():
     """identifies the kernel sources a profile was taken with (profiles/*.json carry the same field)"""
     h = hashlib.sha256()
-    for f in ("kernels.hip", "rt_api.cpp", "bvh_gpu.hip", "bvh_build.cpp", "rt_device.h"):
+    for f in ("kernels.hip", "kernels_beam.inc", "kernels_tile.inc", "rt_api.cpp", "bvh_gpu.hip", "bvh_build.cpp", "rt_device.h", "rt_kernels.h"):
         h.update(open(os.path.join(ROOT, "vulkan_raytracing_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
