@@ -258,7 +258,14 @@ int rt_set_timing(rt_ctx* ctx, int enabled);
  * built once the light and the instances have stood still for two frames and kept until either moves (they do not depend on the camera); "packet_trace" 1 = primary and shadow rays are
  * walked by the packet kernel (one wavefront per 64-ray chunk; default 0: measured slower), 2 = rt_intersect's rays too;
  * "output_bgra8" 1 = like "output_rgba8" in the byte order of a B8G8R8A8 surface (surfaceFormatList[0] is normally that,
- * src/main.cpp:1204, 1899), so that a frame can be compared byte for byte with a screenshot of the original's swapchain image.
+ * src/main.cpp:1204, 1899), so that a frame can be compared byte for byte with a screenshot of the original's swapchain image;
+ * round 4: "pixel_beams" 1 (default) = the primary rays of a pixel share one walk (k_beam: boxes against the beam of the pixel's samples, triangles
+ * per ray; frames without far rays), 0 = one walk per ray; "camera_records" 0 = no entry records for the primary rays (the light-side records stay);
+ * "dead_shadow_rays" 1 (default) = a shadow ray whose outcome cannot change its sample (diffuse and specular exactly 0: the same bits lit or
+ * shadowed) is settled when it is made and not walked — it still counts in rt_stats::rays_shadow, rays_shadow_untraced says how many — 0 = every
+ * shadow ray is walked; "shadow_beams" 1 = the shadow rays of the primary hits in beams as well (k_beam_shadow; default 0: measured slower);
+ * "jitter_table" 1 (default) = k_raygen reads the sample positions of a frame size from a table made once, 0 = evaluates the hash per sample and frame;
+ * "tile_blobs" 1 = the nodes and triangle packets of a screen tile staged through LDS (k_blob / k_tile; default 0: measured slower).
  * Results do not depend on any of them. */
 int rt_set_param(rt_ctx* ctx, const char* name, int value);
 

@@ -207,6 +207,7 @@ struct rt_ctx {
   size_t entry_alloc_tiles = 0;
   // tile blobs (rt_device.h; kernels_tile.inc): 1 = k_blob writes, for every tile whose record names an instance, the nodes and triangle packets the tile's beam
   // can touch as one blob, and k_trace_tile walks the tile's primary rays through it in LDS (result-identical; needs entry_points)
+  int camera_records = 1;   // entry records for the primary rays (k_entry's camera view); 0: their walks start at the TLAS root (the light-side records are not affected)
   int dead_shadow_rays = 1; // a shadow ray whose outcome cannot change its sample (diffuse and specular exactly 0) is settled in k_shade; 0: walked like the others
   int shadow_beams = 0; // ... and the shadow rays of the primary hits (k_beam_shadow): result-identical, a third of the node visits, and SLOWER (the rays of a pixel end
                         // at very different times — the first hit ends a ray — so most lanes of a wave wait: profiles/r04_experiments.txt); rt_set_param("shadow_beams", 1)
@@ -899,7 +900,7 @@ int enqueue_frame(rt_ctx* c, int W, int H, int band_rows, int shard, int n_shard
   // Entry lists (k_entry) ride on the coverage mask: same tiles, same camera basis; the one-lane BVH2 kernel only.
   // (a record opens ONE instance's BLAS; where the beam of a tile meets many instances — cfg5's ring of 16 — the TLAS phase of k_entry costs
   // more than the records save: measured 1.86 vs 1.80 ms per frame, profiles/r03_experiments.txt — so records are for scenes of few instances)
-  const bool entry_on = cover_on && c->entry_points && c->cfg.variant == 0 && n_inst1 <= c->entry_max_instances;
+  const bool entry_on = cover_on && c->entry_points && c->camera_records && c->cfg.variant == 0 && n_inst1 <= c->entry_max_instances;
   // far-ray logic in this frame's kernels only if some ray can be far (a re-render does not trust the context's current instance list: it carries the logic)
   bool far_frame = again != nullptr || far_possible(c, u);
   for (int k = 1; k < K && !far_frame; k++) far_frame = far_possible(c, c->batch_uni[k]);   // (against the instances of ALL frames: conservative)
@@ -1257,7 +1258,7 @@ static int create_context(rt_ctx** out_ctx, int device_id, rt_ctx* parent) {
   if (const char* env = getenv("RT_TRACE_BLOCKS_PER_CU")) { int v = atoi(env); if (v > 0 && v <= 8) c->cfg.trace_blocks = c->n_cu * v; }
   if (parent) {
     c->scene = parent->scene;
-    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->dead_shadow_rays = parent->dead_shadow_rays; c->shadow_beams = parent->shadow_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
+    c->cfg = parent->cfg; c->blas_builder = parent->blas_builder; c->tail_mode = parent->tail_mode; c->tail_min_blocks = parent->tail_min_blocks; c->tail_full_grid = parent->tail_full_grid; c->primary_cover = parent->primary_cover; c->jitter_table = parent->jitter_table; c->tile_blobs = parent->tile_blobs; c->pixel_beams = parent->pixel_beams; c->camera_records = parent->camera_records; c->dead_shadow_rays = parent->dead_shadow_rays; c->shadow_beams = parent->shadow_beams; c->entry_points = parent->entry_points; c->shadow_entry = parent->shadow_entry; c->entry_max_instances = parent->entry_max_instances; c->light_tiles = parent->light_tiles; c->out_rgba8 = parent->out_rgba8; c->out_bgra = parent->out_bgra;
   } else {
     c->scene = new Scene();
     c->scene->device = device_id;
@@ -1619,6 +1620,7 @@ int rt_set_param(rt_ctx* c, const char* name, int value) {
   if (k == "jitter_table") { c->jitter_table = value != 0; return RT_OK; }
   if (k == "tile_blobs") { c->tile_blobs = value != 0; return RT_OK; }
   if (k == "pixel_beams") { c->pixel_beams = value != 0; return RT_OK; }
+  if (k == "camera_records") { c->camera_records = value != 0; return RT_OK; }
   if (k == "dead_shadow_rays") { c->dead_shadow_rays = value != 0; return RT_OK; }
   if (k == "shadow_beams") { c->shadow_beams = value != 0; return RT_OK; }
 
