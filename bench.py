@@ -37,6 +37,9 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=6)
+    ap.add_argument("--gather-format", choices=["rgb32f", "rgba8"], default="rgb32f",
+                    help="N > 1: what a rank sends to rank 0 per pixel: 12 bytes of RGB binary32 (default; the assembled frame is bit-identical to the single-GPU frame) "
+                         "or the 4 bytes of the reference's 8-bit storage image (rt_set_param output_rgba8: a third of the xGMI traffic, DESIGN.md §9)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="frame slots per GPU, each with its own stream; the reference keeps swapchainImageCount = minImageCount + 1 frames in "
                          "flight (src/main.cpp:1203, 2790, 2905-2967).  0 = auto: 4 up to two GPUs, 16 from three on — the smaller a rank's "
@@ -207,11 +210,19 @@ class Rig:
             K = self.K = 1
         self.last_k = [1] * P            # frames in the last pass of every slot (its statistics are sums over them)
         self.batched_before = [False] * P
-        self.shards = [torch.zeros((rows_max, W, 4) if K == 1 else (K, rows_max, W, 4), dtype=torch.float32, device=dev) for _ in range(P)]
-        # the gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183)
+        # pixel format of the shards: RGBA binary32 (default), or — sharded runs with --gather-format rgba8 — the 8-bit RGBA of the reference's storage image
+        self.rgba8 = n > 1 and getattr(args, "gather_format", "rgb32f") == "rgba8"
+        dt = torch.uint8 if self.rgba8 else torch.float32
+        self.esize = 1 if self.rgba8 else 4
+        if self.rgba8:
+            for c in self.ctxs:
+                c.set_param("output_rgba8", 1)
+        self.shards = [torch.zeros((rows_max, W, 4) if K == 1 else (K, rows_max, W, 4), dtype=dt, device=dev) for _ in range(P)]
+        # the binary32 gather carries RGB only: alpha is exactly 1.0 in every pixel (sum of spp ones divided by spp, src/shader.rgen:180-183); the 8-bit one all four bytes
         root_rank = rank == 0 and collective
-        self.gathered = [torch.zeros((n, rows_max, W, 3) if K == 1 else (n, K, rows_max, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
-        self.full = [torch.zeros((H, W, 3) if K == 1 else (K, H, W, 3), dtype=torch.float32, device=dev) if root_rank else None for _ in range(P)]
+        ch = self.ch = 4 if self.rgba8 else 3
+        self.gathered = [torch.zeros((n, rows_max, W, ch) if K == 1 else (n, K, rows_max, W, ch), dtype=dt, device=dev) if root_rank else None for _ in range(P)]
+        self.full = [torch.zeros((H, W, ch) if K == 1 else (K, H, W, ch), dtype=dt, device=dev) if root_rank else None for _ in range(P)]
         self.perm = None
         if root_rank:
             src = np.zeros(H, np.int64)
@@ -237,7 +248,7 @@ class Rig:
             c.set_instances(self.wl.animate(self.time_param), update=True)
             c.set_uniforms(self.wl.uniforms)
         with torch.cuda.stream(self.streams[j]):
-            c.trace_shard(W, H, self.band, rank, n, self.shards[j].data_ptr(), self.shards[j].numel() * 4, self.streams[j].cuda_stream)
+            c.trace_shard(W, H, self.band, rank, n, self.shards[j].data_ptr(), self.shards[j].numel() * self.esize, self.streams[j].cuda_stream)
             if n > 1 and a.rehearse_on_one_gpu:
                 self.streams[j].synchronize()
                 host_shard = self.shards[j].cpu()
@@ -255,15 +266,15 @@ class Rig:
         frame order there.  Enqueued on the current stream, behind the shard's kernels."""
         n, rank, W = self.n, self.rank, self.wl.width
         buf = self.shards[j]
-        rgb = buf[..., :3].contiguous()
+        rgb = buf if self.rgba8 else buf[..., :3].contiguous()
         dist.gather(rgb, list(self.gathered[j].unbind(0)) if rank == 0 else None, dst=0)
         if rank != 0:
             return
         if self.K == 1:
-            torch.index_select(self.gathered[j].view(n * self.rows_max, W, 3), 0, self.perm, out=self.full[j])
+            torch.index_select(self.gathered[j].view(n * self.rows_max, W, self.ch), 0, self.perm, out=self.full[j])
             self.frames[j] = self.full[j]
         else:   # (shard, frame, row) -> (frame, shard * rows_max + row) -> frame rows
-            g = self.gathered[j].permute(1, 0, 2, 3, 4).reshape(self.K, n * self.rows_max, W, 3)
+            g = self.gathered[j].permute(1, 0, 2, 3, 4).reshape(self.K, n * self.rows_max, W, self.ch)
             torch.index_select(g, 1, self.perm, out=self.full[j])
             self.frames[j] = self.full[j][b - 1]
 
@@ -287,8 +298,8 @@ class Rig:
         self.last_k[j] = b
         with torch.cuda.stream(self.streams[j]):
             buf = self.shards[j]
-            c.trace_shard_batch(W, H, self.band, rank, n, buf.data_ptr(), buf.numel() * 4, self.streams[j].cuda_stream,
-                                frame_stride_bytes=self.rows_max * W * 16)
+            c.trace_shard_batch(W, H, self.band, rank, n, buf.data_ptr(), buf.numel() * self.esize, self.streams[j].cuda_stream,
+                                frame_stride_bytes=self.rows_max * W * 4 * self.esize)
             if self.collective:
                 self._gather(j, b)
             else:
@@ -663,6 +674,7 @@ def main(args):
                              "ray_classes": "value counts every traceRayEXT-equivalent: primary + secondary (bounce) + shadow rays; 'secondary' in the metric string means both",
                              "parallelism": "interleaved %d-row bands over %d GPU(s), one scene per GPU, one RCCL gather per %s, %d frame slots in flight per GPU" % (
                                  rig.band, n, "frame" if rig.K == 1 else "pass of %d frames" % rig.K, P),
+                             "gather_format": ("rgba8 (the reference's 8-bit storage image: 4 bytes per pixel)" if rig.rgba8 else "rgb32f (12 bytes per pixel)") if n > 1 else None,
                              "frames_in_flight": P, "frames_per_pass": rig.K, "in_passes_of_8": batched_info, "device": ctx.device_info,
                              "frame_batches": None if rig.K == 1 else "rt_set_batch + rt_trace_shard_batch: %d consecutive frames (own instances, camera and light each) go through one pass "
                                               "of the pipeline; a rank's 1/N shard of ONE frame is eight launches at their latency floors" % rig.K,
@@ -681,7 +693,7 @@ def main(args):
         # (1) isolated frames: the same shard, one frame at a time on slot 0, HIP events around every kernel
         iso = []
         for _ in range(5):
-            ctx.trace_shard(W, H, rig.band, rank, n, rig.shards[0].data_ptr(), rig.shards[0].numel() * 4, rig.streams[0].cuda_stream)
+            ctx.trace_shard(W, H, rig.band, rank, n, rig.shards[0].data_ptr(), rig.shards[0].numel() * rig.esize, rig.streams[0].cuda_stream)
             iso.append(ctx.stats())
         iso_ms = sorted(x.ms_trace_closest for x in iso)[len(iso) // 2]
         mark("isolated frames done")
@@ -810,6 +822,8 @@ def main(args):
         result["roofline"] = roof
         if last_frame is not None:
             img = last_frame.cpu().numpy()
+            if img.dtype == np.uint8:   # --gather-format rgba8
+                img = img.astype(np.float32) / np.float32(255.0)
             if img.shape[-1] == 3:   # assembled multi-rank frame: RGB + the constant alpha
                 img = np.concatenate([img, np.ones(img.shape[:2] + (1,), np.float32)], axis=-1)
             with open(args.save_image, "wb") as fh:

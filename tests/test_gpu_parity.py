@@ -376,6 +376,20 @@ def test_bench_two_ranks_on_one_gpu_reassemble_the_same_frame(tmp_path):
     assert open(c, "rb").read() == open(b, "rb").read()
     fa, fb = open(a, "rb").read(), open(b, "rb").read()
     assert len(fa) == len(fb) and fa == fb
+    # --gather-format rgba8: the ranks render the reference's 8-bit storage image (rt_set_param output_rgba8) and send 4 bytes per pixel —
+    # the assembled frame is the binary32 frame quantised as the imageStore to an 8-bit image does (clamp, x 255, round)
+    d = str(tmp_path / "two_rgba8.pfm")
+    r = subprocess.run([sys.executable, os.path.join(scenes.ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--gather-format", "rgba8",
+                        "--no-cpu-baseline", "--no-extras", "--rehearse-on-one-gpu", "--save-image", d], env={k: v for k, v in env.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")},
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "rgba8" in json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])["config"]["gather_format"]
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("image_diff", os.path.join(scenes.ROOT, "tools", "image_diff.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    f32, f8 = mod.read_image(a), mod.read_image(d)
+    q = (np.clip(f32, 0.0, 1.0) * np.float32(255.0) + np.float32(0.5)).astype(np.uint8)
+    assert np.array_equal(np.rint(f8 * 255.0).astype(np.uint8), q)
 
 
 def test_bench_rccl_gather_path_single_rank(tmp_path):
