@@ -1633,6 +1633,66 @@ def test_pixel_beams_are_result_identical(ctx):
     both(256, 256)
 
 
+def test_pixel_beams_and_settled_shadow_rays_on_random_scenes(ctx):
+    """The two paths the headline rests on, on 24 seeded random scenes: random cameras (position on a shell around the scene, looking at
+    a random point of it, random roll and non-orthonormal basis in a third of the cases), 2-5 instances of teapot / cube with random
+    rotation, non-uniform scale (0.3 .. 2.5), shear or mirroring and position, random object types (diffuse / mirror / glass), random
+    light position, 1..8 samples, frame sizes that do not fill their tiles.  For every scene: frames and ray counts per class with
+    pixel beams and shadow settlement on == both off == the oracle's (every third scene; the others compare the two GPU paths only)."""
+    rng = np.random.default_rng(20260405)
+    paths = [os.path.join(RES, "teapot.obj"), os.path.join(RES, "cube.obj")]
+    geom = host.SceneGeometry(paths)
+
+    def rot(axis, ang):
+        a = np.asarray(axis, np.float64); a /= np.linalg.norm(a)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+    seen = {"shadow": 0, "secondary": 0, "settled": 0, "hit": 0}
+    try:
+        for case in range(24):
+            n_inst = int(rng.integers(2, 6))
+            inst = np.zeros(n_inst, scenes.INSTANCE_DTYPE)
+            for k in range(n_inst):
+                M = rot(rng.normal(size=3), rng.uniform(-3.0, 3.0)) @ np.diag(rng.uniform(0.3, 2.5, size=3))
+                kind = rng.integers(0, 4)
+                if kind == 1:
+                    M = M @ np.array([[1.0, rng.uniform(-0.6, 0.6), 0.0], [0.0, 1.0, 0.0], [rng.uniform(-0.4, 0.4), 0.0, 1.0]])   # shear
+                elif kind == 2:
+                    M = M @ np.diag([-1.0, 1.0, 1.0])                                                                               # mirrored
+                t = rng.uniform(-5.0, 5.0, size=3)
+                inst[k] = host.make_instance(np.concatenate([M, t[:, None]], axis=1).astype(np.float32).reshape(12), int(k != 0), int(rng.integers(0, 2)))
+            u = host.default_uniforms(max_bounce_count=int(rng.integers(0, 4)), samples_per_pixel=int(rng.choice([1, 2, 3, 4, 4, 4, 5, 8])),
+                                      center_object_type=int(rng.integers(0, 3)), orbiting_object_type=int(rng.choice([0, 0, 1, 2])),
+                                      orbiting_object_primitive_offset=geom.orbiting_primitive_offset, orbiting_object_vertex_offset=geom.orbiting_vertex_offset)
+            d = rng.normal(size=3); d /= np.linalg.norm(d)
+            pos = d * rng.uniform(6.0, 30.0)
+            target = rng.uniform(-3.0, 3.0, size=3)
+            fwd = target - pos; fwd /= np.linalg.norm(fwd)
+            up0 = rng.normal(size=3); right = np.cross(fwd, up0); right /= np.linalg.norm(right); up = np.cross(right, fwd)
+            if case % 3 == 2:          # a basis that is neither orthogonal nor normalised (the reference's camera can be set to anything)
+                right = right * rng.uniform(0.7, 1.4) + 0.15 * up; up = up * rng.uniform(0.7, 1.3) - 0.1 * fwd
+            u[0]["position"][:3] = pos; u[0]["forward"][:3] = fwd; u[0]["right"][:3] = right; u[0]["up"][:3] = up
+            u[0]["light_position"][:3] = rng.uniform(-15.0, 15.0, size=3)
+            sp = scenes.ScenePair(paths, inst, u, sky=scenes.synthetic_skybox(64), ctx=ctx)
+            W, H = int(rng.choice([160, 203, 256])), int(rng.choice([96, 117, 144]))
+            out = {}
+            for on in (1, 0):
+                ctx.set_param("pixel_beams", on); ctx.set_param("dead_shadow_rays", on)
+                img, st = ctx.trace(W, H)
+                out[on] = (img, (st.rays_primary, st.rays_secondary, st.rays_shadow), st.rays_shadow_untraced)
+            assert np.array_equal(out[1][0], out[0][0]) and out[1][1] == out[0][1], (case, out[1][1], out[0][1])
+            seen["shadow"] += out[1][1][2]; seen["secondary"] += int(out[1][1][1] > 0); seen["settled"] += out[1][2]; seen["hit"] += int(out[1][1][2] > 0)
+            if case % 3 == 0:
+                ref, rc = sp.orc.render(W, H)
+                check_image(out[1][0], ref)
+                assert out[1][1] == (int(rc[0]), int(rc[1]), int(rc[2])), case
+        # (the scenes are not empty: most cameras see something diffuse, some see mirrors or glass, shadow rays are settled and walked)
+        assert seen["hit"] >= 10 and seen["secondary"] >= 4 and 0 < seen["settled"] < seen["shadow"], seen
+    finally:
+        ctx.set_param("pixel_beams", 1); ctx.set_param("dead_shadow_rays", 1)
+
+
 def test_shadow_rays_that_cannot_change_their_sample_are_settled_in_k_shade(ctx):
     """src/shader.rgen:107-128 traces a shadow ray for every diffuse hit and adds `pow(0.9, i) * (diffuse + specular)` if the light is
     visible.  Where the surface AND the half vector face away from the light both terms are exactly 0: tmpColor stays Iamb*ka whether the
